@@ -1,0 +1,213 @@
+/*
+ * rtn.h — C-ABI of librtn.so: the MI355X (gfx950) RetinaNet detection hot path.
+ *
+ * The reference (jabhinav/RetinaNet-for-Table-Detection) has no FFI layer: the path is
+ * Python calling Keras/TensorFlow.  Each entry point below replaces the TF/Keras/NumPy
+ * work done at the cited reference lines; the Python host in
+ * `retinanet-for-table-detection_amd/model/` keeps the reference's call surface and binds
+ * these symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - every entry returns int: 0 = RTN_OK, <0 = RTN_E*; rtn_last_error(h) gives the text.
+ *   - the CALLER owns every buffer (device memory unless a parameter says "host");
+ *     the library never allocates outputs.  Work is enqueued on the handle's stream and
+ *     returns without synchronising.
+ *   - activations are NHWC; "elements" are units of the tensor dtype.
+ *   - all device pointers must be 16-byte aligned unless stated otherwise.
+ */
+#ifndef RTN_H
+#define RTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTN_OK            0
+#define RTN_EINVAL       -1   /* bad argument / shape the kernels do not support        */
+#define RTN_EHIP         -2   /* a HIP runtime call failed (text has hipGetErrorString) */
+#define RTN_ENOMEM       -3   /* caller-provided workspace too small                     */
+#define RTN_EBOUNDS      -4   /* described access would leave a caller buffer           */
+
+typedef struct rtn_ctx* rtn_handle_t;
+
+typedef enum { RTN_BF16 = 0, RTN_F32 = 1 } rtn_dtype_t;
+
+#define RTN_MAX_GROUPS 5      /* pyramid levels P3..P7 in one grouped launch */
+#define RTN_MAX_GT     64     /* ground-truth boxes per image (anchor targets) */
+#define RTN_MAX_DET    300    /* reference max_detections (model/layers.py:277) */
+
+/* ---- lifetime ------------------------------------------------------------------- */
+int  rtn_create(rtn_handle_t* out, int device);
+int  rtn_destroy(rtn_handle_t h);
+/* stream: a hipStream_t (as void*); NULL = the default stream. */
+int  rtn_set_stream(rtn_handle_t h, void* stream);
+const char* rtn_last_error(rtn_handle_t h);
+const char* rtn_version(void);
+
+/* ---- convolution (implicit GEMM on MFMA) ---------------------------------------------
+ * Replaces every keras.layers.Conv2D / keras_resnet conv executed by TF:
+ *   model/defineModel.py:101-117,155-163 (head stacks), :183-203 (FPN),
+ *   :376-380 (keras_resnet backbone; frozen BN folded into w/bias by the host).
+ *
+ * out[b, oy, ox, n] = act( bias[n] + res(...) +
+ *        sum_{kh,kw,c} in[b, oy*sy - pad_t + kh, ox*sx - pad_l + kw, c] * w[n, (kh*KW+kw)*Crun + c] )
+ * Out-of-image taps read zero (TF zero padding; pad_t/pad_l carry TF 'same' asymmetry,
+ * i.e. pad_before = floor(pad_total/2), SURVEY §8a notes).
+ *
+ * A launch covers up to RTN_MAX_GROUPS "groups" that share w/bias (the pyramid levels of a
+ * head layer, model/defineModel.py:217); ordinary layers use one group.
+ */
+#define RTN_CONV_RELU         0x01  /* max(x,0) after bias+residual                        */
+#define RTN_CONV_SIGMOID      0x02  /* 1/(1+exp(-x))  (model/defineModel.py:123)           */
+#define RTN_CONV_RES_SAME     0x04  /* += res[b,oy,ox,n]  (keras Add; ResNet shortcut)     */
+#define RTN_CONV_RES_UPSAMPLE 0x08  /* += res[b, floor(oy*rs_h), floor(ox*rs_w), n]:
+                                       UpsampleLike + Add, model/layers.py:89-98,
+                                       model/defineModel.py:184,189-190,195                */
+#define RTN_CONV_OUT_F32      0x10  /* store f32 even when dtype is bf16                   */
+
+typedef struct {
+    const void* in;          /* NHWC activations                                       */
+    void*       out;
+    const void* res;         /* residual source or NULL                                */
+    int64_t in_elems;        /* size of the `in` buffer (bounds validation)            */
+    int64_t out_elems;       /* size of the `out` buffer                               */
+    int64_t res_elems;
+    int64_t in_img_stride;   /* elements between images of `in`                        */
+    int64_t out_img_stride;  /* elements between images of `out`                       */
+    int64_t out_off;         /* element offset of this group inside an image of `out`
+                                (level offset of the concatenated head output,
+                                model/defineModel.py:217)                              */
+    int64_t res_img_stride;
+    int32_t in_row_stride;   /* elements between rows of `in`                          */
+    int32_t Hin, Win;        /* taps with iy>=Hin or ix>=Win (or <0) read zero         */
+    int32_t Hout, Wout;
+    int32_t Hres, Wres;      /* residual map extent (RES_UPSAMPLE)                     */
+    int32_t res_ld;          /* elements per pixel of `res`                            */
+} rtn_conv_group_t;
+
+typedef struct {
+    rtn_conv_group_t g[RTN_MAX_GROUPS];
+    int32_t ngroups;
+    int32_t batch;
+    int32_t dtype;           /* rtn_dtype_t of in / w / res (and out unless OUT_F32)   */
+    const void*  w;          /* [w_rows][Ktot], K contiguous; rows >= N are zero       */
+    const float* bias;       /* [w_rows] f32 or NULL                                   */
+    int32_t w_rows;          /* N rounded up to a multiple of 128                      */
+    int32_t N;               /* valid output channels                                  */
+    int32_t KH, KW;
+    int32_t Crun;            /* contiguous input elements per tap: Cin for ordinary
+                                layers (power of two, Crun*sizeof >= 128 B); 32 for the
+                                packed stem (rtn_stem_pack)                            */
+    int32_t pix_stride;      /* elements between horizontally adjacent taps (= Cin;
+                                4 for the packed stem)                                 */
+    int32_t sy, sx;          /* stride                                                 */
+    int32_t pad_t, pad_l;
+    int32_t out_ld;          /* elements per output pixel (= N for NHWC; 4*A / K*A for
+                                the head outputs)                                      */
+    int32_t flags;
+} rtn_conv_desc_t;
+
+int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
+
+/* ---- stem input packing ------------------------------------------------------------
+ * NHWC C=3 image batch -> zero-padded [B][Hp][Wp][4] so that the 7x7/2 stem conv
+ * (keras_resnet conv1 + ZeroPadding2D(3)) becomes an implicit GEMM with one
+ * contiguous 32-element run per kernel row.  Hp = H+6 rounded so 2*(Hout-1)+8 <= Hp,
+ * Wp likewise and even.  src_dtype: RTN_F32, RTN_BF16, or 2 = uint8 (then the reference
+ * normalisation x/127.5-1 is fused: model/utils.py:43-46, model/Parameters.py:23-24).
+ */
+int rtn_stem_pack(rtn_handle_t h, const void* src, int src_dtype, void* dst, int dst_dtype,
+                  int B, int H, int W, int Hp, int Wp);
+
+/* ---- MaxPool 3x3 / 2, TF 'same' (keras_resnet pool1; -inf padding) ----------------- */
+int rtn_maxpool3x3s2_tfsame_fwd(rtn_handle_t h, const void* in, void* out, int dtype,
+                                int B, int Hin, int Win, int C);
+
+/* ---- elementwise ReLU (C6_relu, model/defineModel.py:202) --------------------------- */
+int rtn_relu(rtn_handle_t h, const void* in, void* out, int dtype, int64_t n);
+
+/* ---- anchors ------------------------------------------------------------------------
+ * Host helper: the 9 base anchors of one level, f64 (x1,y1,x2,y2), bit-identical to
+ * generate_anchors (model/anchors.py:243-278).  ratios/scales are the float32-valued
+ * parameters promoted to f64 (model/anchors.py:31-32).
+ */
+int rtn_generate_anchors(double base_size, const double* ratios, int nratios,
+                         const double* scales, int nscales, double* out /* [nr*ns][4] */);
+
+typedef struct {
+    int32_t nlevels;
+    int32_t A;                               /* anchors per cell                          */
+    int32_t H[RTN_MAX_GROUPS], W[RTN_MAX_GROUPS];   /* guess_shapes, model/anchors.py:155 */
+    int32_t stride[RTN_MAX_GROUPS];
+    int32_t anchor_off[RTN_MAX_GROUPS + 1];  /* first anchor index of each level          */
+    double  base[RTN_MAX_GROUPS][16][4];     /* base anchors per level (f64)              */
+} rtn_anchor_cfg_t;
+
+/* Materialise anchors_for_shape (model/anchors.py:169-204): out is f64 [N][4] (device). */
+int rtn_anchors_f64(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, double* out);
+/* The in-graph float32 Anchors layer (model/layers.py:42-53, model/utils.py:51-80). */
+int rtn_anchors_f32(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, float* out);
+
+/* ---- anchor -> ground-truth assignment -----------------------------------------------
+ * Replaces anchor_targets_bbox + compute_gt_annotations + compute_overlap +
+ * bbox_transform (model/anchors.py:36-117,282-313; model/utils.py:180-211), f64 math,
+ * f32 IoU compare, first-max argmax: bit-exact with the NumPy reference.
+ *   gt_boxes  : device f64 [B][RTN_MAX_GT][4]   (x1,y1,x2,y2)
+ *   gt_labels : device i32 [B][RTN_MAX_GT]
+ *   gt_count  : device i32 [B]
+ *   img_hw    : device i32 [B][2]  each image's own (unpadded) height,width
+ *               (model/anchors.py:85-90)
+ *   regression_batch : device f32 [B][N][5];  labels_batch : device f32 [B][N][K+1]
+ */
+int rtn_anchor_targets(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, int num_classes,
+                       const double* gt_boxes, const int32_t* gt_labels,
+                       const int32_t* gt_count, const int32_t* img_hw,
+                       double negative_overlap, double positive_overlap,
+                       float* regression_batch, float* labels_batch);
+
+/* ---- focal + smooth-L1 (model/losses.py:5-46, 49-91) --------------------------------
+ * fwd: sums[0] = sum of focal terms over non-ignored anchors, sums[1] = sum of smooth-L1
+ * terms over positive anchors, sums[2] = number of positive anchors (state == 1); the
+ * caller divides by max(1, count) (all-reduced across ranks under data parallelism so the
+ * normaliser is the merged-batch count).  `sums` is device f64[4].
+ * bwd: d_cls = dLoss/dclassification * inv_norm_cls (w.r.t. the PROBABILITY, or w.r.t.
+ * the pre-sigmoid logit when wrt_logits != 0), d_reg = dLoss/dregression * inv_norm_reg.
+ */
+int rtn_retina_loss_fwd(rtn_handle_t h, int64_t rows /* B*N */, int num_classes,
+                        const float* labels_batch, const float* regression_batch,
+                        const float* classification, const float* regression,
+                        float alpha, float gamma, float sigma, double* sums,
+                        void* workspace, size_t workspace_bytes);
+size_t rtn_retina_loss_workspace_bytes(int64_t rows);
+int rtn_retina_loss_bwd(rtn_handle_t h, int64_t rows, int num_classes,
+                        const float* labels_batch, const float* regression_batch,
+                        const float* classification, const float* regression,
+                        float alpha, float gamma, float sigma,
+                        float inv_norm_cls, float inv_norm_reg, int wrt_logits,
+                        float* d_cls, float* d_reg);
+
+/* ---- decode + clip + score threshold + NMS + top-k + pad ---------------------------
+ * Replaces Anchors/RegressBoxes/ClipBoxes/FilterDetections for num_classes = K with
+ * class_specific_filter=True, nms=True (model/layers.py:42-53,136-138,157-171,177-264;
+ * model/utils.py:84-112).  Anchors are recomputed from the index in float32 exactly as
+ * the in-graph Anchors layer does; boxes are clipped to [0,W]x[0,H] of the padded canvas.
+ *   regression     : device f32 [B][N][4]
+ *   classification : device f32 [B][N][K]
+ *   boxes [B][max_det][4] f32, scores [B][max_det] f32, labels [B][max_det] i32 (pad -1)
+ */
+size_t rtn_detect_workspace_bytes(int B, int64_t N, int num_classes);
+int rtn_decode_filter_nms(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, int num_classes,
+                          const float* regression, const float* classification,
+                          int canvas_h, int canvas_w,
+                          float score_threshold, float nms_threshold, int max_detections,
+                          float* boxes, float* scores, int32_t* labels,
+                          void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTN_H */

@@ -1,0 +1,159 @@
+"""oracle/ref_net.py — CPU restatement (PyTorch-CPU, fp32 or fp64) of the reference's TF graph.
+
+TEST INFRASTRUCTURE ONLY (see oracle/ref_numpy.py header).  "Parity unpinned": the reference holds
+no fixture for network numerics and Keras/TF/keras_resnet are not installed, so this restates
+  * keras_resnet ResNet50/101/152(include_top=False, freeze_bn=True)  — third-party, un-vendored,
+    unpinned by the reference (call sites model/defineModel.py:2-3,376-380); structure as published
+    by keras-resnet 0.1/0.2: ZeroPadding2D(3) + 7x7/2 'conv1' (no bias) + frozen BN
+    (eps 1e-5) + ReLU + MaxPool 3x3/2 'same'; bottleneck_2d blocks [3,4,6,3] / [3,4,23,3] / [3,8,36,3]
+    with the stride on the FIRST 1x1 of block 0 of stages >= 1 and explicit pad-1 3x3 convs;
+  * the FPN  model/defineModel.py:170-205, UpsampleLike model/layers.py:89-98 (legacy TF nearest);
+  * the head submodels model/defineModel.py:78-167 and their concatenation :208-228.
+TF semantics restated: padding='same' (pad_before = floor(pad_total/2)), resize_images(NEAREST,
+align_corners=False): src = min(floor(dst * (in/out) [f32]), in-1).
+
+Weights come in a Keras-style state dict: '<layer>/kernel' HWIO, '<layer>/bias',
+'<bn>/gamma|beta|moving_mean|moving_variance'.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+STAGE_BLOCKS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet152": [3, 8, 36, 3]}
+NUMERICAL = {"resnet50": [False] * 4, "resnet101": [False, True, True, False], "resnet152": [False, True, True, False]}
+
+
+def block_char(backbone, stage, block):
+    if block > 0 and NUMERICAL[backbone][stage]:
+        return "b%d" % block
+    return chr(ord("a") + block)
+
+
+def same_pads(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class RefNet:
+    def __init__(self, state, backbone="resnet50", num_classes=1, num_anchors=9, dtype=torch.float32, emulate_bf16=False):
+        self.backbone = backbone
+        self.K = num_classes
+        self.A = num_anchors
+        self.dtype = dtype
+        self.emu = emulate_bf16
+        self.s = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in state.items()}
+
+    # ---- primitives
+    def _q(self, x):
+        return _bf16(x) if self.emu else x
+
+    def conv(self, x, name, stride=1, pad="same", bn=None, relu=False, res=None, keep_f32=False):
+        w = self.s[name + "/kernel"]                       # HWIO
+        b = self.s.get(name + "/bias")
+        kh, kw = w.shape[0], w.shape[1]
+        wt = w.permute(3, 2, 0, 1).contiguous()            # OIHW
+        bias = b
+        if bn is not None:                                 # frozen BN: y = g (x - m) / sqrt(v + eps) + beta
+            g, beta = self.s[bn + "/gamma"], self.s[bn + "/beta"]
+            m, v = self.s[bn + "/moving_mean"], self.s[bn + "/moving_variance"]
+            scale = g / torch.sqrt(v + BN_EPS)
+            shift = beta - m * scale
+            if self.emu:                                   # the product folds the scale into the bf16 weights
+                wt = wt * scale.view(-1, 1, 1, 1)
+                bias = shift if bias is None else bias * scale + shift
+                scale = None
+        if self.emu:
+            wt = _bf16(wt)
+        if pad == "same":
+            pt, pb = same_pads(x.shape[2], kh, stride)
+            pl, pr = same_pads(x.shape[3], kw, stride)
+        else:
+            pt = pb = pl = pr = int(pad)
+        x = F.pad(x, (pl, pr, pt, pb))
+        y = F.conv2d(x, wt, None, stride=stride)
+        if bn is not None and not self.emu:
+            y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            if bias is not None:
+                raise ValueError("conv with both bias and BN is not part of the graph")
+        elif bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        if res is not None:
+            y = y + res
+        if relu:
+            y = torch.relu(y)
+        return y if keep_f32 else self._q(y)
+
+    @staticmethod
+    def maxpool_same(x):
+        pt, pb = same_pads(x.shape[2], 3, 2)
+        pl, pr = same_pads(x.shape[3], 3, 2)
+        x = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
+        return F.max_pool2d(x, 3, 2)
+
+    @staticmethod
+    def upsample_like(src, target):
+        ih, iw, oh, ow = src.shape[2], src.shape[3], target.shape[2], target.shape[3]
+        sh = np.float32(ih) / np.float32(oh)
+        sw = np.float32(iw) / np.float32(ow)
+        ys = np.minimum(np.floor(np.arange(oh, dtype=np.float32) * sh).astype(np.int64), ih - 1)
+        xs = np.minimum(np.floor(np.arange(ow, dtype=np.float32) * sw).astype(np.int64), iw - 1)
+        return src[:, :, torch.as_tensor(ys)][:, :, :, torch.as_tensor(xs)]
+
+    # ---- graph
+    def backbone_features(self, x):
+        x = self.conv(x, "conv1", stride=2, pad=3, bn="bn_conv1", relu=True)
+        x = self.maxpool_same(x)
+        feats = []
+        filters = 64
+        for stage, nblocks in enumerate(STAGE_BLOCKS[self.backbone]):
+            for block in range(nblocks):
+                sc = str(stage + 2)
+                bc = block_char(self.backbone, stage, block)
+                stride = 2 if (block == 0 and stage > 0) else 1
+                y = self.conv(x, "res%s%s_branch2a" % (sc, bc), stride=stride, pad=0, bn="bn%s%s_branch2a" % (sc, bc), relu=True)
+                y = self.conv(y, "res%s%s_branch2b" % (sc, bc), stride=1, pad=1, bn="bn%s%s_branch2b" % (sc, bc), relu=True)
+                if block == 0:
+                    short = self.conv(x, "res%s%s_branch1" % (sc, bc), stride=stride, pad=0, bn="bn%s%s_branch1" % (sc, bc))
+                else:
+                    short = x
+                x = self.conv(y, "res%s%s_branch2c" % (sc, bc), stride=1, pad=0, bn="bn%s%s_branch2c" % (sc, bc), relu=True, res=short)
+            feats.append(x)
+            filters *= 2
+        return feats                                        # C2..C5
+
+    def pyramid(self, C3, C4, C5):
+        P5r = self.conv(C5, "C5_reduced")
+        P5 = self.conv(P5r, "P5")
+        P4m = self.conv(C4, "C4_reduced", res=self.upsample_like(P5r, C4))
+        P4 = self.conv(P4m, "P4")
+        P3m = self.conv(C3, "C3_reduced", res=self.upsample_like(P4m, C3))
+        P3 = self.conv(P3m, "P3")
+        P6 = self.conv(C5, "P6", stride=2)
+        P7 = self.conv(torch.relu(P6), "P7", stride=2)
+        return [P3, P4, P5, P6, P7]
+
+    def head(self, f, prefix, n_out, sigmoid):
+        y = f
+        for i in range(4):
+            y = self.conv(y, "%s_%d" % (prefix, i), relu=True)
+        y = self.conv(y, prefix, keep_f32=True)
+        y = y.permute(0, 2, 3, 1).reshape(y.shape[0], -1, n_out)
+        return torch.sigmoid(y) if sigmoid else y
+
+    def forward(self, images_nhwc):
+        """images (B,H,W,3) -> regression (B,N,4), classification (B,N,K)."""
+        x = torch.as_tensor(np.asarray(images_nhwc)).to(self.dtype).permute(0, 3, 1, 2).contiguous()
+        x = self._q(x)
+        _, C3, C4, C5 = self.backbone_features(x)
+        feats = self.pyramid(C3, C4, C5)
+        reg = torch.cat([self.head(f, "pyramid_regression", 4, False) for f in feats], dim=1)
+        cls = torch.cat([self.head(f, "pyramid_classification", self.K, True) for f in feats], dim=1)
+        return reg, cls

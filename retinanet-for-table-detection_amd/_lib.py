@@ -1,0 +1,142 @@
+"""ctypes binding of librtn.so (the C-ABI declared in include/rtn.h).
+
+There is no CPU fallback: if the shared library is missing or a symbol is absent the import
+raises, and every call checks its return code and raises RtnError with rtn_last_error().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtn.so")
+
+RTN_BF16, RTN_F32, RTN_U8 = 0, 1, 2
+RTN_MAX_GROUPS, RTN_MAX_GT, RTN_MAX_DET = 5, 64, 300
+
+CONV_RELU, CONV_SIGMOID, CONV_RES_SAME, CONV_RES_UPSAMPLE, CONV_OUT_F32 = 0x01, 0x02, 0x04, 0x08, 0x10
+
+ERRNAMES = {0: "RTN_OK", -1: "RTN_EINVAL", -2: "RTN_EHIP", -3: "RTN_ENOMEM", -4: "RTN_EBOUNDS"}
+
+
+class RtnError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s (%d): %s" % (ERRNAMES.get(code, "RTN_E?"), code, text))
+        self.code = code
+
+
+class ConvGroup(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("out", C.c_void_p), ("res", C.c_void_p),
+        ("in_elems", C.c_int64), ("out_elems", C.c_int64), ("res_elems", C.c_int64),
+        ("in_img_stride", C.c_int64), ("out_img_stride", C.c_int64), ("out_off", C.c_int64),
+        ("res_img_stride", C.c_int64),
+        ("in_row_stride", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hres", C.c_int32), ("Wres", C.c_int32),
+        ("res_ld", C.c_int32),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("g", ConvGroup * RTN_MAX_GROUPS),
+        ("ngroups", C.c_int32), ("batch", C.c_int32), ("dtype", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("w_rows", C.c_int32), ("N", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+        ("Crun", C.c_int32), ("pix_stride", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
+        ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("out_ld", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class AnchorCfg(C.Structure):
+    _fields_ = [
+        ("nlevels", C.c_int32), ("A", C.c_int32),
+        ("H", C.c_int32 * RTN_MAX_GROUPS), ("W", C.c_int32 * RTN_MAX_GROUPS),
+        ("stride", C.c_int32 * RTN_MAX_GROUPS),
+        ("anchor_off", C.c_int32 * (RTN_MAX_GROUPS + 1)),
+        ("base", ((C.c_double * 4) * 16) * RTN_MAX_GROUPS),
+    ]
+
+
+# every symbol include/rtn.h declares: (restype, argtypes)
+_P, _I, _I64, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+SIGNATURES = {
+    "rtn_create": (_I, [C.POINTER(_P), _I]),
+    "rtn_destroy": (_I, [_P]),
+    "rtn_set_stream": (_I, [_P, _P]),
+    "rtn_last_error": (C.c_char_p, [_P]),
+    "rtn_version": (C.c_char_p, []),
+    "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
+    "rtn_stem_pack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I]),
+    "rtn_maxpool3x3s2_tfsame_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
+    "rtn_relu": (_I, [_P, _P, _P, _I, _I64]),
+    "rtn_generate_anchors": (_I, [_D, C.POINTER(_D), _I, C.POINTER(_D), _I, C.POINTER(_D)]),
+    "rtn_anchors_f64": (_I, [_P, C.POINTER(AnchorCfg), _P]),
+    "rtn_anchors_f32": (_I, [_P, C.POINTER(AnchorCfg), _P]),
+    "rtn_anchor_targets": (_I, [_P, C.POINTER(AnchorCfg), _I, _I, _P, _P, _P, _P, _D, _D, _P, _P]),
+    "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
+    "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),
+    "rtn_retina_loss_bwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "rtn_detect_workspace_bytes": (_SZ, [_I, _I64, _I]),
+    "rtn_decode_filter_nms": (_I, [_P, C.POINTER(AnchorCfg), _I, _I, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librtn.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C retinanet-for-table-detection_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class Handle:
+    """Owns one rtn_handle_t bound to a device; check() turns error codes into RtnError."""
+
+    def __init__(self, device=0):
+        self._h = _P()
+        rc = lib.rtn_create(C.byref(self._h), int(device))
+        if rc != 0:
+            raise RtnError(rc, "rtn_create(device=%d) failed (no usable GPU?)" % device)
+        self.device = device
+
+    @property
+    def raw(self):
+        return self._h
+
+    def check(self, rc):
+        if rc != 0:
+            raise RtnError(rc, lib.rtn_last_error(self._h).decode("utf-8", "replace"))
+
+    def set_stream(self, stream_ptr):
+        self.check(lib.rtn_set_stream(self._h, _P(stream_ptr)))
+
+    def close(self):
+        if self._h:
+            lib.rtn_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def generate_anchors_f64(base_size, ratios, scales):
+    """Host-side generate_anchors (model/anchors.py:243-278) through the C-ABI."""
+    import numpy as np
+    r = np.ascontiguousarray(ratios, dtype=np.float64)
+    s = np.ascontiguousarray(scales, dtype=np.float64)
+    out = np.zeros((len(r) * len(s), 4), dtype=np.float64)
+    rc = lib.rtn_generate_anchors(float(base_size), r.ctypes.data_as(C.POINTER(_D)), len(r),
+                                  s.ctypes.data_as(C.POINTER(_D)), len(s), out.ctypes.data_as(C.POINTER(_D)))
+    if rc != 0:
+        raise RtnError(rc, "rtn_generate_anchors")
+    return out

@@ -1,0 +1,220 @@
+// rtn_elementwise.hip — context management and the HBM-bound helpers of the conv stack:
+// stem input packing, MaxPool 3x3/2 (TF 'same'), ReLU.
+#include "rtn_internal.h"
+
+extern "C" const char* rtn_version(void) { return "librtn 0.1 (gfx950)"; }
+
+extern "C" int rtn_create(rtn_handle_t* out, int device) {
+    if (!out) return RTN_EINVAL;
+    *out = nullptr;
+    rtn_ctx* h = new (std::nothrow) rtn_ctx();
+    if (!h) return RTN_ENOMEM;
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&h->zero_page, 256);
+    if (e == hipSuccess) e = hipMemset(h->zero_page, 0, 256);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete h;
+        return RTN_EHIP;
+    }
+    h->num_cus = prop.multiProcessorCount;
+    *out = h;
+    return RTN_OK;
+}
+
+extern "C" int rtn_destroy(rtn_handle_t h) {
+    if (!h) return RTN_EINVAL;
+    if (h->zero_page) (void)hipFree(h->zero_page);
+    delete h;
+    return RTN_OK;
+}
+
+extern "C" int rtn_set_stream(rtn_handle_t h, void* stream) {
+    if (!h) return RTN_EINVAL;
+    h->stream = (hipStream_t)stream;
+    return RTN_OK;
+}
+
+extern "C" const char* rtn_last_error(rtn_handle_t h) { return h ? h->err : "null handle"; }
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    const __bf16 hb = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, hb);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// src_dtype: 0 bf16, 1 f32, 2 u8 (normalised x/127.5 - 1, model/utils.py:43-46)
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H,
+                                                        int W, int Hp, int Wp) {
+    const long long total = (long long)B * Hp * Wp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wp);
+        const long long r = i / Wp;
+        const int y = (int)(r % Hp);
+        const int b = (int)(r / Hp);
+        float v[3] = {0.f, 0.f, 0.f};
+        const int sy = y - 3, sx = x - 3;
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+            const long long si = (((long long)b * H + sy) * W + sx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if constexpr (SRC == 0) v[c] = bf16_bits_to_f32(((const unsigned short*)src)[si + c]);
+                else if constexpr (SRC == 1) v[c] = ((const float*)src)[si + c];
+                else v[c] = __fsub_rn(__fdiv_rn((float)((const unsigned char*)src)[si + c], 127.5f), 1.0f);
+            }
+        }
+        if constexpr (DST == RTN_BF16) {
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16_bits(v[2]);
+            ((uint2*)dst)[i] = o;
+        } else {
+            ((float4*)dst)[i] = make_float4(v[0], v[1], v[2], 0.f);
+        }
+    }
+}
+
+// one thread = 16 bytes of channels of one output pixel
+template <int ES>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const char* __restrict__ in, char* __restrict__ out, int B, int Hin,
+                                                           int Win, int C, int Hout, int Wout, int pad_t, int pad_l) {
+    constexpr int CE = 16 / ES;
+    const int cv = C / CE;
+    const long long total = (long long)B * Hout * Wout * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % Wout);
+        r /= Wout;
+        const int oy = (int)(r % Hout);
+        const int b = (int)(r / Hout);
+        float mx[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) mx[j] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - pad_t + kh;
+            if ((unsigned)iy >= (unsigned)Hin) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - pad_l + kw;
+                if ((unsigned)ix >= (unsigned)Win) continue;
+                const uint4 q = *reinterpret_cast<const uint4*>(in + ((((long long)b * Hin + iy) * Win + ix) * C + cc * CE) * ES);
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mx[2 * j] = fmaxf(mx[2 * j], __uint_as_float(w4[j] << 16));
+                        mx[2 * j + 1] = fmaxf(mx[2 * j + 1], __uint_as_float(w4[j] & 0xffff0000u));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], __uint_as_float(w4[j]));
+                }
+            }
+        }
+        uint4 o;
+        if constexpr (ES == 2) {
+            // inputs are bf16 values, so the max is representable: truncation is exact
+            o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+            o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+            o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+            o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+        } else {
+            o.x = __float_as_uint(mx[0]); o.y = __float_as_uint(mx[1]);
+            o.z = __float_as_uint(mx[2]); o.w = __float_as_uint(mx[3]);
+        }
+        *reinterpret_cast<uint4*>(out + i * 16) = o;
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void relu_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long nvec) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        uint4 q = in[i];
+        unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ES == 2) {
+                // negative (sign bit set) halves -> +0
+                const unsigned lo = (w4[j] & 0x8000u) ? 0u : (w4[j] & 0xffffu);
+                const unsigned hi = (w4[j] & 0x80000000u) ? 0u : (w4[j] & 0xffff0000u);
+                w4[j] = lo | hi;
+            } else {
+                w4[j] = (w4[j] & 0x80000000u) ? 0u : w4[j];
+            }
+        }
+        out[i] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+}
+
+inline unsigned grid_for(long long work, int block = 256, int cap = 256 * 8) {
+    long long g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int rtn_stem_pack(rtn_handle_t h, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int H, int W,
+                             int Hp, int Wp) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || B < 1 || H < 1 || W < 1) return rtn_fail(h, RTN_EINVAL, "stem_pack: bad argument");
+    if (src_dtype < 0 || src_dtype > 2 || (dst_dtype != RTN_BF16 && dst_dtype != RTN_F32))
+        return rtn_fail(h, RTN_EINVAL, "stem_pack: bad dtype");
+    if (Hp < H + 6 || Wp < W + 6 || (Wp & 1)) return rtn_fail(h, RTN_EINVAL, "stem_pack: padded extent %dx%d too small for %dx%d", Hp, Wp, H, W);
+    if ((uintptr_t)dst & 15) return rtn_fail(h, RTN_EINVAL, "stem_pack: dst not 16-byte aligned");
+    const long long total = (long long)B * Hp * Wp;
+    dim3 g(grid_for(total)), b(256);
+#define LAUNCH(S, D) hipLaunchKernelGGL((stem_pack_kernel<S, D>), g, b, 0, h->stream, src, dst, B, H, W, Hp, Wp)
+    if (dst_dtype == RTN_BF16) {
+        if (src_dtype == 0) LAUNCH(0, RTN_BF16); else if (src_dtype == 1) LAUNCH(1, RTN_BF16); else LAUNCH(2, RTN_BF16);
+    } else {
+        if (src_dtype == 0) LAUNCH(0, RTN_F32); else if (src_dtype == 1) LAUNCH(1, RTN_F32); else LAUNCH(2, RTN_F32);
+    }
+#undef LAUNCH
+    RTN_CHECK_LAUNCH(h, "stem_pack_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_maxpool3x3s2_tfsame_fwd(rtn_handle_t h, const void* in, void* out, int dtype, int B, int Hin, int Win, int C) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || B < 1 || Hin < 1 || Win < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "maxpool: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "maxpool: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16) return rtn_fail(h, RTN_EINVAL, "maxpool: C=%d is not a whole number of 16-byte chunks", C);
+    if (((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return rtn_fail(h, RTN_EINVAL, "maxpool: pointer not 16-byte aligned");
+    const int Hout = (Hin + 1) / 2, Wout = (Win + 1) / 2;
+    // TF 'same': pad_total = max((out-1)*s + k - in, 0), pad_before = floor(pad_total/2)
+    int pth = (Hout - 1) * 2 + 3 - Hin; if (pth < 0) pth = 0;
+    int ptw = (Wout - 1) * 2 + 3 - Win; if (ptw < 0) ptw = 0;
+    const long long total = (long long)B * Hout * Wout * (C * es / 16);
+    dim3 g(grid_for(total, 256, 256 * 16)), b(256);
+    if (es == 2) hipLaunchKernelGGL((maxpool3x3s2_kernel<2>), g, b, 0, h->stream, (const char*)in, (char*)out, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    else         hipLaunchKernelGGL((maxpool3x3s2_kernel<4>), g, b, 0, h->stream, (const char*)in, (char*)out, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    RTN_CHECK_LAUNCH(h, "maxpool3x3s2_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_relu(rtn_handle_t h, const void* in, void* out, int dtype, int64_t n) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || n < 1) return rtn_fail(h, RTN_EINVAL, "relu: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "relu: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((n * es) % 16 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return rtn_fail(h, RTN_EINVAL, "relu: size/pointer not 16-byte aligned");
+    const long long nvec = n * es / 16;
+    dim3 g(grid_for(nvec)), b(256);
+    if (es == 2) hipLaunchKernelGGL((relu_kernel<2>), g, b, 0, h->stream, (const uint4*)in, (uint4*)out, nvec);
+    else         hipLaunchKernelGGL((relu_kernel<4>), g, b, 0, h->stream, (const uint4*)in, (uint4*)out, nvec);
+    RTN_CHECK_LAUNCH(h, "relu_kernel");
+    return RTN_OK;
+}

@@ -1,0 +1,54 @@
+// rtn_internal.h — shared by the librtn.so translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "rtn.h"
+
+struct rtn_ctx {
+    int device;
+    hipStream_t stream;
+    void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
+    int num_cus;
+    char err[512];
+};
+
+inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
+    if (h) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(h->err, sizeof(h->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define RTN_HIP(h, call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return rtn_fail((h), RTN_EHIP, "%s failed: %s (%s:%d)", #call,                 \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define RTN_CHECK_LAUNCH(h, name)                                                          \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess)                                                              \
+            return rtn_fail((h), RTN_EHIP, "launch of %s failed: %s", name,                \
+                            hipGetErrorString(e_));                                        \
+    } while (0)
+
+static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : 2; }
+
+// bf16 helpers on raw bits (device + host)
+__host__ __device__ static inline float rtn_bf16_to_f32(unsigned short b) {
+    unsigned int u = ((unsigned int)b) << 16;
+    float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    f = __uint_as_float(u);
+#else
+    memcpy(&f, &u, 4);
+#endif
+    return f;
+}

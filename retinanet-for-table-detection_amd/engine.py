@@ -1,0 +1,305 @@
+"""Executor of the RetinaNet graph on librtn.so: one ctypes call per fused layer.
+
+Graph (what a forward pass IS in the reference):
+  resnet_retinanet (model/defineModel.py:357-389) -> keras_resnet backbone C3..C5
+  __create_pyramid_features (:170-205) -> P3..P7
+  regression / classification submodels on every level, concatenated (:208-228, :255-265)
+  retinanet_bbox (:296-353): Anchors -> RegressBoxes -> ClipBoxes -> FilterDetections.
+PyTorch is used for device memory and the stream only; all arithmetic is in the HIP library.
+Frozen BN, bias, ReLU, the residual add, UpsampleLike+Add and the sigmoid are fused into the
+convolution epilogues; the five pyramid levels of a head layer run as ONE grouped launch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import weights as Wt
+
+_TORCH_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+_RTN_DT = {"bf16": L.RTN_BF16, "f32": L.RTN_F32}
+_SRC_DT = {torch.bfloat16: 0, torch.float32: 1, torch.uint8: 2}
+
+
+def same_pad_before(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2
+
+
+class AnchorParams:
+    """model/anchors.py:7-33 values (sizes/strides per level, float32 ratios/scales)."""
+
+    def __init__(self, sizes=(32, 64, 128, 256, 512), strides=(8, 16, 32, 64, 128),
+                 ratios=None, scales=None):
+        self.sizes = list(sizes)
+        self.strides = list(strides)
+        self.ratios = np.array([0.5, 1, 2], np.float32) if ratios is None else np.asarray(ratios)
+        self.scales = (np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)], np.float32)
+                       if scales is None else np.asarray(scales))
+
+    def num_anchors(self):
+        return len(self.ratios) * len(self.scales)
+
+
+def make_anchor_cfg(image_hw, params=None, levels=(3, 4, 5, 6, 7)):
+    """rtn_anchor_cfg_t for a canvas: guess_shapes (model/anchors.py:155-165) + base anchors."""
+    params = params or AnchorParams()
+    cfg = L.AnchorCfg()
+    cfg.nlevels = len(levels)
+    cfg.A = params.num_anchors()
+    off = 0
+    for i, lv in enumerate(levels):
+        h = (int(image_hw[0]) + 2 ** lv - 1) // 2 ** lv
+        w = (int(image_hw[1]) + 2 ** lv - 1) // 2 ** lv
+        cfg.H[i], cfg.W[i], cfg.stride[i] = h, w, params.strides[i]
+        cfg.anchor_off[i] = off
+        off += h * w * cfg.A
+        base = L.generate_anchors_f64(params.sizes[i], params.ratios, params.scales)
+        for a in range(cfg.A):
+            for j in range(4):
+                cfg.base[i][a][j] = float(base[a, j])
+    for i in range(len(levels), L.RTN_MAX_GROUPS + 1):
+        cfg.anchor_off[i] = off
+    return cfg, off
+
+
+class Engine:
+    def __init__(self, backbone="resnet50", num_classes=1, num_anchors=9, dtype="bf16", device=0, anchor_params=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("the RetinaNet engine needs a ROCm GPU: no CPU fallback exists")
+        if backbone.split("_")[0] not in Wt.STAGE_BLOCKS:
+            raise ValueError("Backbone ('{}') not in allowed backbones ({}).".format(backbone, list(Wt.STAGE_BLOCKS)))
+        self.backbone = backbone.split("_")[0]
+        self.K, self.A = int(num_classes), int(num_anchors)
+        self.dtype = dtype
+        self.tdt, self.rdt = _TORCH_DT[dtype], _RTN_DT[dtype]
+        self.device = torch.device("cuda", device)
+        self.h = L.Handle(device)
+        self.anchor_params = anchor_params or AnchorParams()
+        self.w = {}
+        self.plans = {}
+        self.state = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state(self, state):
+        """state: Keras-named dict (see weights.py). Packs every conv (BN folded) onto the device."""
+        self.state = state
+        self.w = {}
+        for (name, kh, kw, cin, cout, has_bias, bn) in Wt.conv_layers(self.backbone, self.K, self.A):
+            bnp = None if bn is None else [state[bn + s] for s in ("/gamma", "/beta", "/moving_mean", "/moving_variance")]
+            bias = state.get(name + "/bias") if has_bias else None
+            pack = Wt.pack_stem if name == "conv1" else Wt.pack_conv
+            wk, bk = pack(state[name + "/kernel"], bias, bnp, self.tdt, self.device)
+            self.w[name] = (wk, bk, kh, kw, cin, cout)
+        self.plans = {}
+
+    # ------------------------------------------------------------------ descriptors
+    def _group(self, x, out, Hout, Wout, res=None, out_off=0, out_img_stride=None, res_hw=None):
+        g = L.ConvGroup()
+        B, Hin, Win, Cin = x.shape
+        g.in_ = x.data_ptr(); g.in_elems = x.numel()
+        g.out = out.data_ptr(); g.out_elems = out.numel()
+        g.in_img_stride = Hin * Win * Cin
+        g.in_row_stride = Win * Cin
+        g.Hin, g.Win, g.Hout, g.Wout = Hin, Win, Hout, Wout
+        g.out_img_stride = out.numel() // B if out_img_stride is None else out_img_stride
+        g.out_off = out_off
+        if res is not None:
+            g.res = res.data_ptr(); g.res_elems = res.numel()
+            g.res_img_stride = res.numel() // B
+            g.res_ld = res.shape[3]
+            g.Hres, g.Wres = (res.shape[1], res.shape[2]) if res_hw is None else res_hw
+        return g
+
+    def _conv(self, name, groups, B, stride=1, pad=(0, 0), flags=0, out_ld=None, rtn_dtype=None):
+        wk, bk, kh, kw, cin, cout = self.w[name]
+        d = L.ConvDesc()
+        for i, g in enumerate(groups):
+            d.g[i] = g
+        d.ngroups, d.batch, d.dtype = len(groups), B, self.rdt
+        d.w, d.bias = wk.data_ptr(), bk.data_ptr()
+        d.w_rows, d.N, d.KH, d.KW = wk.shape[0], cout, kh, kw
+        d.Crun, d.pix_stride = cin, cin
+        d.sy = d.sx = stride
+        d.pad_t, d.pad_l = pad
+        d.out_ld = cout if out_ld is None else out_ld
+        d.flags = flags
+        return ("conv", d, name)
+
+    # ------------------------------------------------------------------ plan
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key in self.plans:
+            return self.plans[key]
+        if self.state is None:
+            raise RuntimeError("load_state() first")
+        dev, tdt = self.device, self.tdt
+        ops, keep = [], []
+
+        def buf(*shape, dtype=None):
+            t = torch.empty(*shape, dtype=dtype or tdt, device=dev)
+            keep.append(t)
+            return t
+
+        # ---- stem: pack to [B][Hp][Wp][4], then 7x7/2 as an 8x1 implicit GEMM over 32-element runs
+        H1, W1 = (H + 1) // 2, (W + 1) // 2
+        Hp = max(H + 6, 2 * (H1 - 1) + 8)
+        Wp = max(W + 6, 2 * (W1 - 1) + 8)
+        Wp += Wp & 1
+        xin = {"B": B, "H": H, "W": W, "Hp": Hp, "Wp": Wp}
+        xp = torch.zeros(B * Hp * Wp * 4 + 64, dtype=tdt, device=dev)     # +64: the last pixel's 32-run stays in bounds
+        keep.append(xp)
+        c1 = buf(B, H1, W1, 64)
+        wk, bk, *_ = self.w["conv1"]
+        d = L.ConvDesc()
+        g = L.ConvGroup()
+        g.in_ = xp.data_ptr(); g.in_elems = xp.numel()
+        g.out = c1.data_ptr(); g.out_elems = c1.numel()
+        g.in_img_stride, g.in_row_stride = Hp * Wp * 4, Wp * 4
+        g.Hin, g.Win, g.Hout, g.Wout = Hp, Wp, H1, W1
+        g.out_img_stride = H1 * W1 * 64
+        d.g[0] = g
+        d.ngroups, d.batch, d.dtype = 1, B, self.rdt
+        d.w, d.bias, d.w_rows, d.N = wk.data_ptr(), bk.data_ptr(), wk.shape[0], 64
+        d.KH, d.KW, d.Crun, d.pix_stride = 8, 1, 32, 4
+        d.sy = d.sx = 2
+        d.pad_t = d.pad_l = 0
+        d.out_ld, d.flags = 64, L.CONV_RELU
+        ops.append(("pack", xp, xin))
+        ops.append(("conv", d, "conv1"))
+        # ---- pool1
+        H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
+        x = buf(B, H2, W2, 64)
+        ops.append(("pool", c1, x, (B, H1, W1, 64)))
+        # ---- bottleneck stages
+        feats = []
+        for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
+            f = 64 * 2 ** stage
+            for block in range(nblocks):
+                s, bname = str(stage + 2), Wt.block_name(self.backbone, stage, block)
+                st = 2 if (block == 0 and stage > 0) else 1
+                Hi, Wi = x.shape[1], x.shape[2]
+                Ho, Wo = (Hi - 1) // st + 1, (Wi - 1) // st + 1
+                a = buf(B, Ho, Wo, f)
+                ops.append(self._conv("res%s%s_branch2a" % (s, bname), [self._group(x, a, Ho, Wo)], B, stride=st, flags=L.CONV_RELU))
+                b2 = buf(B, Ho, Wo, f)
+                ops.append(self._conv("res%s%s_branch2b" % (s, bname), [self._group(a, b2, Ho, Wo)], B, pad=(1, 1), flags=L.CONV_RELU))
+                if block == 0:
+                    sc = buf(B, Ho, Wo, 4 * f)
+                    ops.append(self._conv("res%s%s_branch1" % (s, bname), [self._group(x, sc, Ho, Wo)], B, stride=st))
+                else:
+                    sc = x
+                y = buf(B, Ho, Wo, 4 * f)
+                ops.append(self._conv("res%s%s_branch2c" % (s, bname), [self._group(b2, y, Ho, Wo, res=sc)], B,
+                                      flags=L.CONV_RELU | L.CONV_RES_SAME))
+                x = y
+            feats.append(x)
+        C3, C4, C5 = feats[1], feats[2], feats[3]
+        # ---- FPN (model/defineModel.py:183-203)
+        def hw(t):
+            return t.shape[1], t.shape[2]
+        P5r = buf(B, *hw(C5), 256)
+        ops.append(self._conv("C5_reduced", [self._group(C5, P5r, *hw(C5))], B))
+        P5 = buf(B, *hw(C5), 256)
+        ops.append(self._conv("P5", [self._group(P5r, P5, *hw(C5))], B, pad=(1, 1)))
+        P4m = buf(B, *hw(C4), 256)
+        ops.append(self._conv("C4_reduced", [self._group(C4, P4m, *hw(C4), res=P5r)], B, flags=L.CONV_RES_UPSAMPLE))
+        P4 = buf(B, *hw(C4), 256)
+        ops.append(self._conv("P4", [self._group(P4m, P4, *hw(C4))], B, pad=(1, 1)))
+        P3m = buf(B, *hw(C3), 256)
+        ops.append(self._conv("C3_reduced", [self._group(C3, P3m, *hw(C3), res=P4m)], B, flags=L.CONV_RES_UPSAMPLE))
+        P3 = buf(B, *hw(C3), 256)
+        ops.append(self._conv("P3", [self._group(P3m, P3, *hw(C3))], B, pad=(1, 1)))
+        H6, W6 = (C5.shape[1] + 1) // 2, (C5.shape[2] + 1) // 2
+        P6 = buf(B, H6, W6, 256)
+        ops.append(self._conv("P6", [self._group(C5, P6, H6, W6)], B, stride=2,
+                              pad=(same_pad_before(C5.shape[1], 3, 2), same_pad_before(C5.shape[2], 3, 2))))
+        P6r = buf(B, H6, W6, 256)
+        ops.append(("relu", P6, P6r))
+        H7, W7 = (H6 + 1) // 2, (W6 + 1) // 2
+        P7 = buf(B, H7, W7, 256)
+        ops.append(self._conv("P7", [self._group(P6r, P7, H7, W7)], B, stride=2,
+                              pad=(same_pad_before(H6, 3, 2), same_pad_before(W6, 3, 2))))
+        pyr = [P3, P4, P5, P6, P7]
+        # ---- anchors / outputs
+        cfg, N = make_anchor_cfg((H, W), self.anchor_params)
+        for i, p in enumerate(pyr):
+            if (p.shape[1], p.shape[2]) != (cfg.H[i], cfg.W[i]):
+                raise RuntimeError("pyramid level %d is %s, anchors expect %s" % (i + 3, hw(p), (cfg.H[i], cfg.W[i])))
+        regression = buf(B, N, 4, dtype=torch.float32)
+        classification = buf(B, N, self.K, dtype=torch.float32)
+        # ---- heads: every layer is ONE grouped launch over the five levels (weights shared, :217)
+        for prefix, out_t, per_anchor, last_flags in (("pyramid_regression", regression, 4, L.CONV_OUT_F32),
+                                                      ("pyramid_classification", classification, self.K,
+                                                       L.CONV_OUT_F32 | L.CONV_SIGMOID)):
+            cur = pyr
+            for i in range(4):
+                nxt = [buf(B, *hw(p), 256) for p in pyr]
+                groups = [self._group(ci, ni, *hw(ci)) for ci, ni in zip(cur, nxt)]
+                ops.append(self._conv("%s_%d" % (prefix, i), groups, B, pad=(1, 1), flags=L.CONV_RELU))
+                cur = nxt
+            groups = [self._group(ci, out_t, *hw(ci), out_off=cfg.anchor_off[l] * per_anchor, out_img_stride=N * per_anchor)
+                      for l, ci in enumerate(cur)]
+            ops.append(self._conv(prefix, groups, B, pad=(1, 1), flags=last_flags, out_ld=self.A * per_anchor))
+        ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
+        plan = {"ops": ops, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+                "classification": classification, "pyr": pyr, "feats": feats,
+                "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
+                "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
+                "scores": torch.empty(B, L.RTN_MAX_DET, dtype=torch.float32, device=dev),
+                "labels": torch.empty(B, L.RTN_MAX_DET, dtype=torch.int32, device=dev)}
+        self.plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ run
+    def _bind_stream(self):
+        self.h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def forward(self, images):
+        """images: device tensor (B,H,W,3), float32 / bfloat16 (already normalised) or uint8 (raw 3-channel
+        distance-transform page: the x/127.5-1 of model/utils.py:43-46 is fused into the stem packer).
+        Returns device tensors regression (B,N,4) f32, classification (B,N,K) f32 — the training
+        model's outputs in the reference's order (model/defineModel.py:244-249)."""
+        if images.device.type != "cuda" or images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError("images must be a (B,H,W,3) tensor on the GPU")
+        if images.dtype not in _SRC_DT:
+            raise ValueError("unsupported image dtype %s" % images.dtype)
+        images = images.contiguous()
+        B, H, W, _ = images.shape
+        plan = self._plan(B, H, W)
+        self._bind_stream()
+        lib, h = L.lib, self.h
+        for op in plan["ops"]:
+            kind = op[0]
+            if kind == "conv":
+                h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
+            elif kind == "pack":
+                xi = op[2]
+                h.check(lib.rtn_stem_pack(h.raw, images.data_ptr(), _SRC_DT[images.dtype], op[1].data_ptr(), self.rdt,
+                                          xi["B"], xi["H"], xi["W"], xi["Hp"], xi["Wp"]))
+            elif kind == "pool":
+                Bn, Hi, Wi, Cc = op[3]
+                h.check(lib.rtn_maxpool3x3s2_tfsame_fwd(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
+            elif kind == "relu":
+                h.check(lib.rtn_relu(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, op[1].numel()))
+        return plan["regression"], plan["classification"]
+
+    def detect(self, images, score_threshold=0.05, nms_threshold=0.5, max_detections=300):
+        """Inference model outputs [boxes (B,300,4), scores (B,300), labels (B,300)] (model/defineModel.py:310-315)."""
+        reg, cls = self.forward(images)
+        B, H, W, _ = images.shape
+        plan = self._plan(B, H, W)
+        self.postprocess(plan["cfg"], reg, cls, H, W, plan["boxes"], plan["scores"], plan["labels"], plan["det_ws"],
+                         score_threshold, nms_threshold, max_detections)
+        return plan["boxes"], plan["scores"], plan["labels"]
+
+    def postprocess(self, cfg, regression, classification, H, W, boxes, scores, labels, ws, score_threshold=0.05,
+                    nms_threshold=0.5, max_detections=300):
+        self._bind_stream()
+        B = regression.shape[0]
+        self.h.check(L.lib.rtn_decode_filter_nms(self.h.raw, C.byref(cfg), B, classification.shape[2], regression.data_ptr(),
+                                                  classification.data_ptr(), H, W, score_threshold, nms_threshold,
+                                                  max_detections, boxes.data_ptr(), scores.data_ptr(), labels.data_ptr(),
+                                                  ws.data_ptr(), ws.numel()))

@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: librtn.so loads, exports every symbol include/rtn.h declares,
+the ctypes structs match the header's layout, and host-only entry points give reference answers.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtn.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    lib = C.CDLL(pkg.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "librtn.so does not export %s" % s
+    assert set(syms) == set(pkg._lib.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_struct_layout_matches_header(pkg, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(rtn_conv_group_t),sizeof(rtn_conv_desc_t),sizeof(rtn_anchor_cfg_t),'
+                   'offsetof(rtn_conv_desc_t,w),offsetof(rtn_conv_desc_t,flags),offsetof(rtn_anchor_cfg_t,base));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    L = pkg._lib
+    want = [C.sizeof(L.ConvGroup), C.sizeof(L.ConvDesc), C.sizeof(L.AnchorCfg), L.ConvDesc.w.offset, L.ConvDesc.flags.offset,
+            L.AnchorCfg.base.offset]
+    assert got == want
+
+
+def test_generate_anchors_host_entry(pkg, golden):
+    from oracle import ref_numpy as R
+    for size in (32, 64, 128, 256, 512, 48):
+        got = pkg._lib.generate_anchors_f64(size, R.DEFAULT_RATIOS, R.DEFAULT_SCALES)
+        assert np.array_equal(got, golden["base_%d" % size])
+    # float64 scales take the float64 product path, like NumPy would
+    s64 = np.array([1.0, 2 ** (1 / 3), 2 ** (2 / 3)])
+    assert np.array_equal(pkg._lib.generate_anchors_f64(48, R.DEFAULT_RATIOS, s64), R.base_anchors(48, R.DEFAULT_RATIOS, s64))
+
+
+def test_error_paths_without_gpu(pkg):
+    L = pkg._lib
+    assert L.lib.rtn_version().startswith(b"librtn")
+    assert L.lib.rtn_destroy(None) == -1
+    assert L.lib.rtn_conv2d_fwd(None, None) == -1
+    assert L.lib.rtn_detect_workspace_bytes(0, 10, 1) == 0
+    assert L.lib.rtn_detect_workspace_bytes(2, 1000, 1) > 2 * 1000 * 8
+    bad = (C.c_double * 1)(1.0)
+    assert L.lib.rtn_generate_anchors(32.0, bad, 0, bad, 1, bad) == -1
+
+
+def test_product_does_not_import_oracle():
+    pkgdir = os.path.join(ROOT, "retinanet-for-table-detection_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f

@@ -1,0 +1,221 @@
+"""GPU parity: rtn_conv2d_fwd (implicit GEMM on MFMA) against a float64 torch-CPU convolution that
+restates TF's semantics ('same' padding asymmetry, legacy nearest upsample, fused epilogues).
+Tolerances: fp32 path 2e-5 relative to the output scale (exact-f32 MFMA, different sum order);
+bf16 path compared against the same reference fed bf16-rounded inputs/weights, 1e-2 relative
+(one bf16 rounding of the output, fp32 accumulation)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (torch.float32, 1), "bf16": (torch.bfloat16, 0)}
+
+
+def q(x, dtype):
+    return x.to(DT[dtype][0]).to(torch.float64)
+
+
+def ref_conv(x, w_hwio, bias, stride, pad_t, pad_l, Hout, Wout):
+    """x (B,H,W,C) f64, taps outside the image are zero; output extent given."""
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    H, W = x.shape[1], x.shape[2]
+    pb = max((Hout - 1) * stride + kh - pad_t - H, 0)
+    pr = max((Wout - 1) * stride + kw - pad_l - W, 0)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pad_l, pr, pad_t, pb))
+    y = F.conv2d(xp, w_hwio.permute(3, 2, 0, 1), None, stride=stride)[:, :, :Hout, :Wout]
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def upsample_nearest_legacy(src, oh, ow):
+    ih, iw = src.shape[1], src.shape[2]
+    ys = np.minimum(np.floor(np.arange(oh, dtype=np.float32) * (np.float32(ih) / np.float32(oh))).astype(np.int64), ih - 1)
+    xs = np.minimum(np.floor(np.arange(ow, dtype=np.float32) * (np.float32(iw) / np.float32(ow))).astype(np.int64), iw - 1)
+    return src[:, torch.as_tensor(ys)][:, :, torch.as_tensor(xs)]
+
+
+def pack_w(w_hwio, dtype, dev):
+    kh, kw, cin, cout = w_hwio.shape
+    rows = -(-cout // 128) * 128
+    wk = torch.zeros(rows, kh * kw * cin, dtype=torch.float64)
+    wk[:cout] = w_hwio.permute(3, 0, 1, 2).reshape(cout, -1)
+    return wk.to(DT[dtype][0]).to(dev).contiguous(), rows
+
+
+def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res_mode=None, B=2, seed=0, out_ld=None,
+             concat=False):
+    """levels: list of (H, W). Returns (got list, want list) per level (f64, NHWC)."""
+    L = pkg._lib
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(seed)
+    tdt = DT[dtype][0]
+    w = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin)
+    bias = torch.randn(cout, generator=g, dtype=torch.float64)
+    wq = q(w, dtype)
+    wk, rows = pack_w(w, dtype, dev)
+    bk = torch.zeros(rows, dtype=torch.float32)
+    bk[:cout] = bias.float()
+    bk = bk.to(dev)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, DT[dtype][1]
+    d.w, d.bias, d.w_rows, d.N, d.KH, d.KW = wk.data_ptr(), bk.data_ptr(), rows, cout, k, k
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = stride
+    out_f32 = bool(flags & L.CONV_OUT_F32) or dtype == "f32"
+    odt = torch.float32 if out_f32 else tdt
+    ld = cout if out_ld is None else out_ld
+    d.out_ld = ld
+    keep, wants, outs = [], [], []
+    if concat:                                    # head-output style: all levels into one (B, total, ld) tensor
+        total = sum(((H - 1) // stride + 1) * ((W - 1) // stride + 1) for H, W in levels) if pad != "same" else \
+            sum((-(-H // stride)) * (-(-W // stride)) for H, W in levels)
+        big = torch.full((B, total * ld + 8,), -77.0, dtype=odt, device=dev)
+        keep.append(big)
+    off = 0
+    for gi, (H, W) in enumerate(levels):
+        x = torch.randn(B, H, W, cin, generator=g, dtype=torch.float64)
+        if pad == "same":
+            Ho, Wo = -(-H // stride), -(-W // stride)
+            pt = max((Ho - 1) * stride + k - H, 0) // 2
+            pl = max((Wo - 1) * stride + k - W, 0) // 2
+        else:
+            pt = pl = pad
+            Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        d.pad_t, d.pad_l = pt, pl
+        want = ref_conv(q(x, dtype), wq, bias.float().double(), stride, pt, pl, Ho, Wo)
+        xd = x.to(tdt).to(dev).contiguous()
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, Ho, Wo
+        if res_mode == "same":
+            r = torch.randn(B, Ho, Wo, cout, generator=g, dtype=torch.float64)
+            want = want + q(r, dtype)
+        elif res_mode == "up":
+            rh, rw = max(1, (Ho + 1) // 2), max(1, (Wo + 1) // 2 + (gi % 2))
+            r = torch.randn(B, rh, rw, cout, generator=g, dtype=torch.float64)
+            want = want + upsample_nearest_legacy(q(r, dtype), Ho, Wo)
+        if res_mode:
+            rd = r.to(tdt).to(dev).contiguous()
+            keep.append(rd)
+            grp.res, grp.res_elems = rd.data_ptr(), rd.numel()
+            grp.res_img_stride, grp.res_ld = rd.numel() // B, cout
+            grp.Hres, grp.Wres = rd.shape[1], rd.shape[2]
+        if flags & L.CONV_RELU:
+            want = torch.relu(want)
+        if flags & L.CONV_SIGMOID:
+            want = torch.sigmoid(want)
+        if concat:
+            grp.out, grp.out_elems = big.data_ptr(), big.numel()
+            grp.out_img_stride, grp.out_off = total * ld + 8, off
+            outs.append((off, Ho * Wo))
+            off += Ho * Wo * ld
+        else:
+            od = torch.full((B, Ho, Wo, ld), -77.0, dtype=odt, device=dev)
+            keep.append(od)
+            grp.out, grp.out_elems = od.data_ptr(), od.numel()
+            grp.out_img_stride = Ho * Wo * ld
+            outs.append(od)
+        d.g[gi] = grp
+        keep.append(xd)
+        wants.append(want)
+    d.flags = flags
+    handle.check(L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    gots = []
+    for o, want in zip(outs, wants):
+        if concat:
+            off0, cells = o
+            flat = big.cpu().double()
+            gots.append(flat[:, off0:off0 + cells * ld].reshape(B, want.shape[1], want.shape[2], ld))
+        else:
+            gots.append(o.cpu().double())
+    return gots, wants, ld, cout
+
+
+def check(gots, wants, ld, cout, dtype):
+    tol = 2e-5 if dtype == "f32" else 1e-2
+    for got, want in zip(gots, wants):
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got[..., :cout] - want).abs().max())
+        assert err <= tol * scale, "max err %.3e (scale %.2f)" % (err, scale)
+        if ld > cout:                                  # columns past N are never written
+            assert torch.all(got[..., cout:] == -77.0)
+
+
+CASES = [
+    # (levels, cin, cout, k, stride, pad, flags-names, res)
+    ([(9, 13)], 64, 64, 1, 1, 0, ["RELU"], None),                      # C2 branch2a-like, BN=64 tile
+    ([(12, 20)], 64, 64, 3, 1, 1, ["RELU"], None),                     # 3x3, K step spans taps
+    ([(17, 23)], 256, 128, 1, 2, 0, ["RELU"], None),                   # stride-2 1x1 'valid' (stage entry)
+    ([(10, 11)], 128, 512, 1, 1, 0, ["RELU"], "same"),                 # branch2c + shortcut add
+    ([(25, 42)], 256, 256, 3, 1, "same", [], None),                    # FPN P5
+    ([(25, 42)], 512, 256, 3, 2, "same", [], None),                    # P6: stride 2, asymmetric TF pad
+    ([(13, 21)], 256, 256, 3, 2, "same", [], None),                    # P7
+    ([(20, 33)], 512, 256, 1, 1, 0, [], "up"),                         # lateral + UpsampleLike add (non-integer ratio)
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 3, 1, "same", ["RELU"], None),   # grouped head layer
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_conv_layers(pkg, handle, dtype, case):
+    levels, cin, cout, k, stride, pad, fl, res = CASES[case]
+    L = pkg._lib
+    flags = sum(getattr(L, "CONV_" + f) for f in fl)
+    if res == "same":
+        flags |= L.CONV_RES_SAME
+    elif res == "up":
+        flags |= L.CONV_RES_UPSAMPLE
+    gots, wants, ld, n = run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags, res, seed=case)
+    check(gots, wants, ld, n, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cout,sig", [(36, False), (9, True), (18, True)])
+def test_head_output_concat(pkg, handle, dtype, cout, sig):
+    """pyramid_regression / pyramid_classification: skinny N, f32 output written at level offsets of the
+    concatenated (B, N_anchors, 4|K) tensor (model/defineModel.py:111-123,163-166,217)."""
+    L = pkg._lib
+    flags = L.CONV_OUT_F32 | (L.CONV_SIGMOID if sig else 0)
+    levels = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    gots, wants, ld, n = run_case(pkg, handle, dtype, levels, 256, cout, 3, 1, "same", flags, None, concat=True, seed=7)
+    check(gots, wants, ld, n, dtype)
+
+
+def test_conv_rejects_bad_descriptors(pkg, handle):
+    L = pkg._lib
+    dev = torch.device("cuda")
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
+    o = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, 1, 0
+    d.w, d.w_rows, d.N, d.KH, d.KW, d.Crun, d.pix_stride = w.data_ptr(), 128, 64, 1, 1, 64, 64
+    d.sy = d.sx = 1
+    d.out_ld = 64
+    g = L.ConvGroup()
+    g.in_, g.in_elems, g.out, g.out_elems = x.data_ptr(), x.numel(), o.data_ptr(), o.numel()
+    g.in_img_stride, g.in_row_stride, g.out_img_stride = 4 * 4 * 64, 4 * 64, 4 * 4 * 64
+    g.Hin = g.Win = g.Hout = g.Wout = 4
+    d.g[0] = g
+    assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == 0
+    d.g[0].in_elems = x.numel() - 1                       # taps would leave the buffer
+    assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -4
+    assert b"taps reach" in L.lib.rtn_last_error(handle.raw)
+    d.g[0].in_elems = x.numel()
+    d.g[0].out_elems = o.numel() - 1
+    assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -4
+    d.g[0].out_elems = o.numel()
+    d.Crun = 48                                           # not a power of two
+    assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -1
+    d.Crun = 64
+    d.w_rows = 64                                         # not padded to 128 rows
+    assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -1
+    torch.cuda.synchronize()

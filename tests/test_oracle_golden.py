@@ -1,0 +1,150 @@
+"""CPU tests: the oracle (oracle/ref_numpy.py) against golden vectors produced by the reference's own
+NumPy code (oracle/gen_golden.py) and the known answers recorded in SURVEY.md §8c."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+from helpers import load_case
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(HERE, "golden", "ref_numpy_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("shape", [(800, 1333), (1333, 800), (1028, 800), (1024, 1024), (64, 96), (37, 53)])
+def test_anchors_for_shape_bit_exact(shape, golden, meta):
+    a = R.anchors_for_shape(shape + (3,))
+    m = meta["anchors_%dx%d" % shape]
+    assert a.dtype == np.float64 and a.shape == (m["n"], 4)
+    assert sha16(a) == m["sha16"]
+    assert np.array_equal(a[:18], golden["anchors_%dx%d_head" % shape])
+    assert np.array_equal(a[-18:], golden["anchors_%dx%d_tail" % shape])
+
+
+def test_survey_known_answers():
+    # SURVEY.md §8c
+    a = R.anchors_for_shape((800, 1333, 3))
+    assert a.shape == (200700, 4) and a.sum() == 429287904.0 and sha16(a) == "f0e9c258a40ccb72"
+    np.testing.assert_allclose(a[0], [-18.627417, -7.3137085, 26.627417, 15.3137085], rtol=0, atol=1e-7)
+    assert R.level_shapes((800, 1333, 3)) == [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
+    assert sha16(R.anchors_for_shape((1028, 800, 3))) == "ec22c7193055a26b"
+    assert sha16(R.anchors_for_shape((1024, 1024, 3))) == "da5235c3236615b9"
+    assert float(R.DEFAULT_SCALES[1]) == 1.2599210739135742
+    assert R.compute_resize_scale((2200, 1712, 3)) == 0.4672897196261682
+    assert R.compute_resize_scale((600, 2000, 3)) == 0.6665
+    np.testing.assert_allclose(R.preprocess_custom_tf(np.array([0, 127, 255], np.uint8)),
+                               np.array([-1, -0.00392157, 1], np.float32), rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("size", [32, 64, 128, 256, 512, 48])
+def test_base_anchors(size, golden):
+    assert np.array_equal(R.base_anchors(size), golden["base_%d" % size])
+
+
+def test_overlap_and_argmax(golden):
+    iou = R.compute_overlap(golden["overlap_boxes"], golden["overlap_gt"])
+    assert iou.dtype == np.float32 and np.array_equal(iou, golden["overlap_iou"])
+    anchors = R.anchors_for_shape((800, 1333, 3))
+    ov = R.compute_overlap(anchors, golden["overlap_gt"])
+    assert np.array_equal(ov.max(axis=0), golden["overlap_max_per_gt"])
+    assert np.array_equal(np.bincount(np.argmax(ov, axis=1), minlength=3), golden["overlap_argmax_hist"])
+
+
+TARGET_CASES = ["kat3", "kat2_img800x1000", "empty", "rand0", "rand1", "rand2", "small_tie"]
+
+
+@pytest.mark.parametrize("name", TARGET_CASES)
+def test_anchor_targets_bit_exact(name, golden, meta):
+    canvas, shapes, gts = load_case(golden, name)
+    anchors = R.anchors_for_shape(canvas + (3,))
+    reg, lab = R.anchor_targets(anchors, shapes, gts, [np.zeros(len(g)) for g in gts], 1)
+    assert reg.dtype == np.float32 and lab.dtype == np.float32
+    assert sha16(reg) == meta["tgt_%s" % name]["reg_sha16"]
+    assert sha16(lab) == meta["tgt_%s" % name]["lab_sha16"]
+    for b in range(len(shapes)):
+        assert np.array_equal(np.nonzero(reg[b, :, 4] == 1)[0], golden["tgt_%s_pos%d" % (name, b)])
+        assert np.array_equal(np.nonzero(reg[b, :, 4] == -1)[0], golden["tgt_%s_ign%d" % (name, b)])
+
+
+def test_target_counts_from_survey(golden):
+    # 82 positive / 149 IoU-ignore (+ the 792 cells past the canvas edge that
+    # anchor_targets_bbox also marks -1) for the 3-box KAT; empty image: 0 / 792
+    assert len(golden["tgt_kat3_pos0"]) == 82 and len(golden["tgt_kat3_ign0"]) == 149 + 792
+    assert list(golden["tgt_kat3_pos0"][:4]) == [154145, 154154, 154163, 154172]
+    assert len(golden["tgt_empty_pos0"]) == 0 and len(golden["tgt_empty_ign0"]) == 792
+    assert len(golden["tgt_kat2_img800x1000_pos0"]) == 46
+
+
+def test_resize_and_preprocess(golden):
+    got = np.array([R.compute_resize_scale(tuple(s)) for s in golden["resize_shapes"]])
+    assert np.array_equal(got, golden["resize_scales"])
+    assert np.array_equal(R.preprocess_custom_tf(golden["preprocess_in"]), golden["preprocess_out"])
+
+
+# ---- restated TF-graph pieces: self-consistency (no reference fixture exists: parity unpinned)
+def test_nms_properties():
+    rng = np.random.RandomState(0)
+    xy = rng.uniform(0, 200, size=(400, 2)).astype(np.float32)
+    wh = rng.uniform(5, 80, size=(400, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], axis=1)
+    scores = rng.uniform(0, 1, size=400).astype(np.float32)
+    scores[10] = scores[11]                      # an exact tie
+    sel = R.nms_tf(boxes, scores, 300, 0.5)
+    assert len(set(sel.tolist())) == len(sel)
+    s = scores[sel]
+    assert np.all(s[:-1] >= s[1:])
+    for i, a in enumerate(sel):                  # no kept pair overlaps > 0.5
+        if i:
+            assert not np.any(R._iou_f32(boxes[a], boxes[sel[:i]]) > 0.5)
+    kept = set(sel.tolist())                     # every dropped box is covered by a better kept one
+    for j in range(400):
+        if j not in kept:
+            better = [k for k in sel if (scores[k], -k) > (scores[j], -j)]
+            assert np.any(R._iou_f32(boxes[j], boxes[better]) > 0.5)
+
+
+def test_filter_detections_padding_and_order():
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60]], np.float32)
+    cls = np.array([[0.9], [0.8], [0.04]], np.float32)
+    b, s, l = R.filter_detections(boxes, cls)
+    assert b.shape == (300, 4) and s.shape == (300,) and l.dtype == np.int32
+    assert s[0] == np.float32(0.9) and l[0] == 0 and np.all(s[1:] == -1) and np.all(l[1:] == -1) and np.all(b[1:] == -1)
+
+
+def test_loss_gradients_match_finite_differences():
+    rng = np.random.RandomState(3)
+    N = 60
+    lab = np.zeros((1, N, 2))
+    lab[0, :, 1] = rng.choice([-1, 0, 1], size=N)
+    lab[0, lab[0, :, 1] == 1, 0] = 1
+    p = rng.uniform(0.02, 0.98, size=(1, N, 1))
+    tot, npos, g = R.focal_loss(lab, p, grad=True)
+    eps = 1e-6
+    for i in range(0, N, 7):
+        pp = p.copy(); pp[0, i, 0] += eps
+        pm = p.copy(); pm[0, i, 0] -= eps
+        fd = (R.focal_loss(lab, pp)[0] - R.focal_loss(lab, pm)[0]) / (2 * eps)
+        assert abs(fd - g[0, i, 0]) < 1e-5 * max(1, abs(fd))
+    reg_t = np.zeros((1, N, 5))
+    reg_t[0, :, :4] = rng.normal(size=(N, 4))
+    reg_t[0, :, 4] = lab[0, :, 1]
+    pred = reg_t[0:1, :, :4] + rng.normal(scale=0.2, size=(1, N, 4))
+    tot, npos, g = R.smooth_l1_loss(reg_t, pred, grad=True)
+    for i in range(0, N, 5):
+        for j in range(4):
+            pp = pred.copy(); pp[0, i, j] += eps
+            pm = pred.copy(); pm[0, i, j] -= eps
+            fd = (R.smooth_l1_loss(reg_t, pp)[0] - R.smooth_l1_loss(reg_t, pm)[0]) / (2 * eps)
+            assert abs(fd - g[0, i, j]) < 1e-5 * max(1, abs(fd))
