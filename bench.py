@@ -1,0 +1,172 @@
+"""bench.py — images/sec of the RetinaNet R50-FPN detection path at 800x1333 on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+(N > 1 is launched by the driver with torch.distributed.run, one rank per GPU.)
+
+Workload (BASELINE.json configs[1]): ResNet50-FPN RetinaNet INFERENCE, 800x1333, bf16, batch 8 per GPU:
+one step = stem pack -> ResNet-50 -> FPN -> both head stacks over P3..P7 -> decode + score threshold + NMS + top-k
+for a batch of 8 synthetic 3-channel distance-transform-like pages already resident in HBM.  Inference shards by
+image with no data-path collective ("scaling": "weak": per-GPU batch fixed).  Weights are seeded random-init of the
+architecture (no checkpoint exists in the reference); the classification bias is set so ~1 % of the 200,700 anchors
+per image pass the 0.05 score threshold, the load a trained detector puts on the NMS stage.
+
+The JSON line also carries
+  roofline     — the dominant kernel (conv_igemm_kernel, bf16 MFMA): algorithmic FLOPs of all its launches in a step
+                 / their summed duration measured with events on the launch stream; per-launch averages alongside.
+  cpu_baseline — the oracle (oracle/ref_net.py + ref_numpy.py: torch-CPU fp32 restatement, kind "port") timed on this
+                 host's cores on a bounded sample (whole path for 1 image of the same canvas).
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "retinanet-for-table-detection_amd"
+
+CANVAS = (800, 1333)
+BATCH = 8
+GFLOP_PER_IMAGE = 416.1            # 208.06 GMAC forward, every conv counted
+BF16_DENSE_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+CAND_FRACTION = 0.01               # share of anchors above the 0.05 score threshold (set by calibration)
+CLS_BIAS = -5.27                   # default used by tools/ when no calibration runs
+
+
+def synth_images(torch, B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.clamp(torch.empty(B, CANVAS[0], CANVAS[1], 3).exponential_(1 / 12.0, generator=g) *
+                      torch.rand(B, CANVAS[0], CANVAS[1], 3, generator=g), 0, 255).round()
+    x = raw / 127.5 - 1.0                                      # model/utils.py:43-46
+    return x.to(torch.bfloat16).to(device)
+
+
+def conv_flops(op_desc, batch):
+    """Algorithmic FLOPs of one conv launch: 2 * M * N * (true taps * Cin)."""
+    d = op_desc
+    k_true = 7 * 7 * 3 if (d.Crun == 32 and d.pix_stride == 4) else d.KH * d.KW * d.Crun
+    m = sum(d.g[i].Hout * d.g[i].Wout for i in range(d.ngroups)) * batch
+    return 2.0 * m * d.N * k_true
+
+
+def cpu_baseline(torch, state, threads):
+    import numpy as np
+    from oracle import ref_numpy as R
+    from oracle.ref_net import RefNet
+    torch.set_num_threads(threads)
+    x = synth_images(torch, 1, 123, "cpu").float().numpy()
+    net = RefNet(state, dtype=torch.float32)
+    a32 = R.anchors_f32(CANVAS + (3,))
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        with torch.no_grad():
+            reg, cls = net.forward(x)
+        boxes = R.decode_boxes_f32(a32, reg.numpy()[0], CANVAS)
+        R.filter_detections(boxes, cls.numpy()[0])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 3:
+            break
+    return {"value": n / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d x (1 image 800x1333: fp32 torch-CPU forward + NumPy decode/NMS), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    E = importlib.import_module(PKG + ".engine")
+    Wt = importlib.import_module(PKG + ".weights")
+    x = synth_images(torch, BATCH, 1000 + rank, device)
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16", device=local_rank)
+    # calibration (untimed): choose the classification bias so that CAND_FRACTION of the anchors clear the 0.05 score
+    # threshold on this input, i.e. the NMS stage sees a trained detector's load rather than 0 or 200,700 candidates.
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=0.0, tame=True)
+    eng.load_state(state)
+    _, cls0 = eng.forward(x[:1])
+    logit = torch.log(cls0 / (1 - cls0)).flatten().float()
+    q = torch.quantile(logit[::7], 1.0 - CAND_FRACTION).item()
+    cls_bias = math.log(0.05 / 0.95) - q
+    state["pyramid_classification/bias"] = (state["pyramid_classification/bias"] * 0 + cls_bias).astype("float32")
+    eng.load_state(state)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.detect(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        boxes, scores, labels = eng.detect(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_gpus = world
+    images = n_gpus * BATCH * args.steps
+    value = images / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: events around every conv launch of extra (untimed) steps
+        plan = eng._plan(BATCH, CANVAS[0], CANVAS[1])
+        conv_ops = [op for op in plan["ops"] if op[0] == "conv"]
+        flops_step = sum(conv_flops(op[1], BATCH) for op in conv_ops)
+        reps = 3
+        per_op_ms = eng.profile_ops(x, reps=reps)
+        conv_ms = sum(ms for kind, ms in per_op_ms if kind == "conv") / reps
+        other_ms = sum(ms for kind, ms in per_op_ms if kind != "conv") / reps
+        achieved = flops_step / (conv_ms * 1e-3) / 1e12
+        ncand = int((plan["classification"] > 0.05).sum().item())
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16>", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": len(conv_ops), "avg_launch_ms": conv_ms / len(conv_ops),
+                    "flop_per_step": flops_step, "conv_ms_per_step": conv_ms, "non_conv_ms_per_step": other_ms}
+        out = {"metric": "images/sec RetinaNet R50-FPN 800x1333 inference", "value": value, "unit": "images/sec",
+               "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "ResNet50-FPN RetinaNet inference 800x1333 bf16 batch 8/GPU incl. decode+NMS "
+                                      "(BASELINE.json configs[1])",
+                          "batch_per_gpu": BATCH, "canvas": list(CANVAS), "anchors_per_image": plan["N"],
+                          "candidates_above_0.05_per_image": ncand / BATCH, "parallelism": "dp%d (images sharded, no collective)" % n_gpus,
+                          "gflop_per_image_survey": GFLOP_PER_IMAGE, "gflop_per_image_counted": flops_step / BATCH / 1e9},
+               "roofline": roofline}
+        if not args.no_cpu_baseline and n_gpus == 1:
+            threads = min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(torch, state, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

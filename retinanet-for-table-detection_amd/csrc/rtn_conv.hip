@@ -26,11 +26,20 @@ constexpr int NT = 256;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;   // beyond every buffer: the hardware range check returns zeros
+
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 struct KGroup {
     const char* in;
     char* out;
     const char* res;
+    unsigned in_bytes;          // size of `in` (buffer descriptor range)
     long long in_img_stride_b;  // bytes
     long long out_img_stride;   // elements
     long long out_off;          // elements
@@ -47,7 +56,7 @@ struct KParams {
     KGroup g[RTN_MAX_GROUPS];
     const char* w;
     const float* bias;
-    const char* zero;
+    unsigned w_bytes;
     int ngroups, ntiles_n;
     int N, Kbytes, nkt;
     int cshift, crun_mask, kw_inv, KW;
@@ -58,6 +67,21 @@ struct KParams {
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
+}
+
+template <int ES>
+__device__ __forceinline__ void mma_step(f32x4& acc, const uint4& a, const uint4& b) {
+    if constexpr (ES == 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    } else {
+        // exact f32: the lane holds k = 4*kq + e of a 16-wide k group; step e pairs equal k of A and B
+        const f32x4 af = __builtin_bit_cast(f32x4, a);
+        const f32x4 bf = __builtin_bit_cast(f32x4, b);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+    }
 }
 
 template <int ES, int BN>
@@ -100,8 +124,14 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
     const int c = t & 7, r0 = t >> 3;
     const int st_off = r0 * 128 + ((c ^ (r0 & 7)) << 4);   // LDS byte offset of this thread's chunk
 
-    // ---- per-thread A rows (4 output pixels), fixed for the whole K loop
-    long long rowbase[4];
+    // ---- per-thread A rows (4 output pixels), fixed for the whole K loop.  Taps are fetched with
+    // range-checked buffer loads: an out-of-image tap gets OOB_OFFSET and the hardware returns zeros
+    // (no branch, no select on pointers — hipcc turns those into a branch + vmcnt(0) per load).
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)G.in, 0, (int)__builtin_amdgcn_readfirstlane((int)G.in_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.w, 0, (int)__builtin_amdgcn_readfirstlane((int)p.w_bytes), 0x00020000);
+    unsigned rowbase[4];
     int iy0[4], ix0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -113,44 +143,46 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
             const int ox = rem - oy * Wout;
             iy0[i] = oy * p.sy - p.pad_t;
             ix0[i] = ox * p.sx - p.pad_l;
-            rowbase[i] = (long long)b * G.in_img_stride_b + (long long)iy0[i] * G.in_row_stride_b +
-                         (long long)ix0[i] * p.pix_stride_b;
+            // modulo-2^32 arithmetic: only offsets of in-image taps (which fit, host-checked) are ever used
+            rowbase[i] = (unsigned)((long long)b * G.in_img_stride_b + (long long)iy0[i] * G.in_row_stride_b +
+                                    (long long)ix0[i] * p.pix_stride_b);
         } else {
             iy0[i] = -(1 << 28);
             ix0[i] = 0;
             rowbase[i] = 0;
         }
     }
-    const char* wrow = p.w + (long long)(n0 + r0) * p.Kbytes + c * 16;
+    const unsigned wbase = (unsigned)(n0 + r0) * (unsigned)p.Kbytes + (unsigned)c * 16u;
+    const unsigned wstep = 32u * (unsigned)p.Kbytes;
+    const int Hin = G.Hin, Win = G.Win, in_row_stride_b = G.in_row_stride_b;
 
     uint4 ra[4], rb[NB];
-    auto load_tile = [&](int kt) {
-        const int kb = kt * 128 + c * 16;
-        const int k0 = kb >> ESH;
-        const int kpos = k0 >> p.cshift;
-        const int coff = k0 & p.crun_mask;
-        const int kh = (kpos * p.kw_inv) >> 16;
-        const int kw = kpos - kh * p.KW;
-        const long long delta = (long long)kh * G.in_row_stride_b + kw * p.pix_stride_b + coff * ES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = iy0[i] + kh, ix = ix0[i] + kw;
-            const bool ok = (unsigned)iy < (unsigned)G.Hin && (unsigned)ix < (unsigned)G.Win;
-            const char* ptr = ok ? (G.in + rowbase[i] + delta) : p.zero;
-            ra[i] = *reinterpret_cast<const uint4*>(ptr);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            rb[i] = *reinterpret_cast<const uint4*>(wrow + (long long)(32 * i) * p.Kbytes + kt * 128);
-    };
-    auto store_tile = [&](int buf) {
-        char* A = lds + buf * A_BYTES;
-        char* B = lds + 2 * A_BYTES + buf * B_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(A + st_off + i * 32 * 128) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(B + st_off + i * 32 * 128) = rb[i];
-    };
+#define RTN_LOAD_TILE(KT)                                                                               \
+    {                                                                                                   \
+        const int kb_ = (KT) * 128 + c * 16;                                                            \
+        const int k0_ = kb_ >> ESH;                                                                     \
+        const int kpos_ = k0_ >> p.cshift;                                                              \
+        const int coff_ = k0_ & p.crun_mask;                                                            \
+        const int kh_ = (kpos_ * p.kw_inv) >> 16;                                                       \
+        const int kw_ = kpos_ - kh_ * p.KW;                                                             \
+        const unsigned delta_ = (unsigned)(kh_ * in_row_stride_b + kw_ * p.pix_stride_b + coff_ * ES);  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                              \
+            const int iy_ = iy0[i_] + kh_, ix_ = ix0[i_] + kw_;                                         \
+            const bool ok_ = (unsigned)iy_ < (unsigned)Hin && (unsigned)ix_ < (unsigned)Win;            \
+            ra[i_] = buffer_load16(in_rsrc, ok_ ? rowbase[i_] + delta_ : OOB_OFFSET);                   \
+        }                                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                               \
+            rb[i_] = buffer_load16(w_rsrc, wbase + (unsigned)i_ * wstep + (unsigned)(KT) * 128u);       \
+    }
+#define RTN_STORE_TILE(BUF)                                                                             \
+    {                                                                                                   \
+        char* A_ = lds + (BUF) * A_BYTES;                                                               \
+        char* B_ = lds + 2 * A_BYTES + (BUF) * B_BYTES;                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                \
+            *reinterpret_cast<uint4*>(A_ + st_off + i_ * 32 * 128) = ra[i_];                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                               \
+            *reinterpret_cast<uint4*>(B_ + st_off + i_ * 32 * 128) = rb[i_];                            \
+    }
 
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 15, kq = lane >> 4;
@@ -165,51 +197,42 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute_tile = [&](int buf) {
-        const char* A = lds + buf * A_BYTES + a_row_off;
-        const char* B = lds + 2 * A_BYTES + buf * B_BYTES + b_row_off;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int rd = ks ? rd1 : rd0;
-            uint4 a[MI], b[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const uint4*>(A + i * 16 * 128 + rd);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const uint4*>(B + j * 16 * 128 + rd);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if constexpr (ES == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        // exact f32: lane holds k = 4*kq + e of a 16-wide k group; step e pairs equal k of A and B
-                        const f32x4 af = __builtin_bit_cast(f32x4, a[i]);
-                        const f32x4 bf = __builtin_bit_cast(f32x4, b[j]);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
-    };
+#define RTN_COMPUTE_TILE(BUF)                                                                           \
+    {                                                                                                   \
+        const char* A_ = lds + (BUF) * A_BYTES + a_row_off;                                             \
+        const char* B_ = lds + 2 * A_BYTES + (BUF) * B_BYTES + b_row_off;                               \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                           \
+            const int rd_ = ks_ ? rd1 : rd0;                                                            \
+            uint4 a_[MI], b_[NI];                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                           \
+                a_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rd_);                     \
+            _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_)                                           \
+                b_[j_] = *reinterpret_cast<const uint4*>(B_ + j_ * 16 * 128 + rd_);                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                           \
+                _Pragma("unroll") for (int j_ = 0; j_ < NI; ++j_) mma_step<ES>(acc[i_][j_], a_[i_], b_[j_]); \
+        }                                                                                               \
+    }
 
     // ---- main loop
     const int nkt = p.nkt;
-    load_tile(0);
-    store_tile(0);
+    RTN_LOAD_TILE(0);
+    RTN_STORE_TILE(0);
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = (kt + 1 < nkt);
-        if (more) load_tile(kt + 1);
-        compute_tile(cur);
-        if (more) store_tile(cur ^ 1);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // even step: compute buffer 0 while the loads of step kt+1 fly, then stage them into buffer 1
+        if (kt + 1 < nkt) RTN_LOAD_TILE(kt + 1);
+        RTN_COMPUTE_TILE(0);
+        if (kt + 1 < nkt) RTN_STORE_TILE(1);
         __syncthreads();
-        cur ^= 1;
+        if (kt + 1 >= nkt) break;
+        if (kt + 2 < nkt) RTN_LOAD_TILE(kt + 2);
+        RTN_COMPUTE_TILE(1);
+        if (kt + 2 < nkt) RTN_STORE_TILE(0);
+        __syncthreads();
     }
+#undef RTN_LOAD_TILE
+#undef RTN_STORE_TILE
+#undef RTN_COMPUTE_TILE
 
     // ---- epilogue: accumulators -> LDS (f32), then whole-row stores
     float* S = reinterpret_cast<float*>(lds);
@@ -376,7 +399,7 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         const long long in_max = (long long)(d->batch - 1) * s.in_img_stride + (long long)(s.Hin - 1) * s.in_row_stride +
                                  (long long)(s.Win - 1) * d->pix_stride + d->Crun;
         if (in_max > s.in_elems) return rtn_fail(h, RTN_EBOUNDS, "conv: group %d taps reach element %lld of a %lld-element input", i, in_max, (long long)s.in_elems);
-        if (s.in_elems * es >= (1ll << 40)) return rtn_fail(h, RTN_EINVAL, "conv: input too large");
+        if (s.in_elems * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "conv: group %d input of %lld bytes exceeds the 4 GiB buffer-descriptor range", i, (long long)s.in_elems * es);
         const long long cells = (long long)s.Hout * s.Wout;
         const long long M = cells * d->batch;
         if (M > (1ll << 30)) return rtn_fail(h, RTN_EINVAL, "conv: M too large");
@@ -394,6 +417,7 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         g.in = (const char*)s.in;
         g.out = (char*)s.out;
         g.res = (const char*)s.res;
+        g.in_bytes = (unsigned)(s.in_elems * es);
         g.in_img_stride_b = s.in_img_stride * es;
         g.out_img_stride = s.out_img_stride;
         g.out_off = s.out_off;
@@ -412,7 +436,8 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
     const int BN = d->N <= 64 ? 64 : 128;
     p.w = (const char*)d->w;
     p.bias = d->bias;
-    p.zero = (const char*)h->zero_page;
+    if ((long long)d->w_rows * Ktot * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "conv: weights exceed the 4 GiB buffer-descriptor range");
+    p.w_bytes = (unsigned)((long long)d->w_rows * Ktot * es);
     p.ngroups = d->ngroups;
     p.ntiles_n = (d->N + BN - 1) / BN;
     p.N = d->N;

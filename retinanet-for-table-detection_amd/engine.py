@@ -270,21 +270,49 @@ class Engine:
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)
         self._bind_stream()
-        lib, h = L.lib, self.h
         for op in plan["ops"]:
-            kind = op[0]
-            if kind == "conv":
-                h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
-            elif kind == "pack":
-                xi = op[2]
-                h.check(lib.rtn_stem_pack(h.raw, images.data_ptr(), _SRC_DT[images.dtype], op[1].data_ptr(), self.rdt,
-                                          xi["B"], xi["H"], xi["W"], xi["Hp"], xi["Wp"]))
-            elif kind == "pool":
-                Bn, Hi, Wi, Cc = op[3]
-                h.check(lib.rtn_maxpool3x3s2_tfsame_fwd(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
-            elif kind == "relu":
-                h.check(lib.rtn_relu(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, op[1].numel()))
+            self._run_op(op, images)
         return plan["regression"], plan["classification"]
+
+    def _run_op(self, op, images):
+        lib, h = L.lib, self.h
+        kind = op[0]
+        if kind == "conv":
+            h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
+        elif kind == "pack":
+            xi = op[2]
+            h.check(lib.rtn_stem_pack(h.raw, images.data_ptr(), _SRC_DT[images.dtype], op[1].data_ptr(), self.rdt,
+                                      xi["B"], xi["H"], xi["W"], xi["Hp"], xi["Wp"]))
+        elif kind == "pool":
+            Bn, Hi, Wi, Cc = op[3]
+            h.check(lib.rtn_maxpool3x3s2_tfsame_fwd(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
+        elif kind == "relu":
+            h.check(lib.rtn_relu(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, op[1].numel()))
+        else:
+            raise RuntimeError("unknown op %r" % (kind,))
+
+    def profile_ops(self, images, reps=1):
+        """Per-op device time: events recorded on the launch stream around every op of `reps` forward passes.
+        Returns [(kind, total_ms_over_reps)] in execution order, plus ("detect", ms) for the post-processing."""
+        images = images.contiguous()
+        B, H, W, _ = images.shape
+        plan = self._plan(B, H, W)
+        self._bind_stream()
+        ops = plan["ops"]
+        totals = [0.0] * (len(ops) + 1)
+        for _ in range(reps):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 2)]
+            evs[0].record()
+            for i, op in enumerate(ops):
+                self._run_op(op, images)
+                evs[i + 1].record()
+            self.postprocess(plan["cfg"], plan["regression"], plan["classification"], H, W, plan["boxes"], plan["scores"],
+                             plan["labels"], plan["det_ws"])
+            evs[-1].record()
+            torch.cuda.synchronize()
+            for i in range(len(ops) + 1):
+                totals[i] += evs[i].elapsed_time(evs[i + 1])
+        return [(op[0], totals[i]) for i, op in enumerate(ops)] + [("detect", totals[-1])]
 
     def detect(self, images, score_threshold=0.05, nms_threshold=0.5, max_detections=300):
         """Inference model outputs [boxes (B,300,4), scores (B,300), labels (B,300)] (model/defineModel.py:310-315)."""

@@ -54,12 +54,15 @@ def conv_layers(backbone="resnet50", num_classes=1, num_anchors=9, feature_size=
     return out
 
 
-def init_state(backbone="resnet50", num_classes=1, num_anchors=9, seed=0, randomize_bn=False, cls_bias=None):
+def init_state(backbone="resnet50", num_classes=1, num_anchors=9, seed=0, randomize_bn=False, cls_bias=None, tame=False):
     """Seeded random weights following the Keras initialisers the reference gets by default
     (SURVEY.md §8a notes): keras_resnet convs he_normal, BN gamma 1 / beta 0 / mean 0 / var 1;
     FPN convs glorot_uniform + zero bias (model/defineModel.py:183-203); head convs N(0, 0.01) +
     zero bias, classification output bias -log((1-p)/p), p = 0.01 (model/initializers.py:19-22).
-    randomize_bn / cls_bias are test knobs (exercise BN folding; put scores above the 0.05 threshold)."""
+    randomize_bn / cls_bias / tame are test knobs: exercise BN folding; put scores above the 0.05 threshold;
+    `tame` makes the random network well conditioned like a trained one (small gamma on the last BN of every
+    residual block so the residual stream does not double per block, He-scaled head kernels so the regression
+    outputs are O(1) instead of O(0.01)) — noise comparisons against the oracle are only meaningful then."""
     g = torch.Generator().manual_seed(seed)
     st = {}
     for (name, kh, kw, cin, cout, has_bias, bn) in conv_layers(backbone, num_classes, num_anchors):
@@ -67,7 +70,12 @@ def init_state(backbone="resnet50", num_classes=1, num_anchors=9, seed=0, random
         if bn is not None:
             w = torch.randn(kh, kw, cin, cout, generator=g) * math.sqrt(2.0 / fan_in)
         elif name.startswith("pyramid_"):
-            w = torch.randn(kh, kw, cin, cout, generator=g) * 0.01
+            std = 0.01
+            if tame:
+                # He scaling keeps the O(8) pyramid magnitude through the stack; the output layers bring it to O(1)
+                std = (math.sqrt(1.0 / fan_in) / 8.0 if name in ("pyramid_regression", "pyramid_classification")
+                       else math.sqrt(2.0 / fan_in))
+            w = torch.randn(kh, kw, cin, cout, generator=g) * std
         else:
             lim = math.sqrt(6.0 / (fan_in + fan_out))
             w = (torch.rand(kh, kw, cin, cout, generator=g) * 2 - 1) * lim
@@ -79,7 +87,10 @@ def init_state(backbone="resnet50", num_classes=1, num_anchors=9, seed=0, random
             st[name + "/bias"] = b.numpy()
         if bn is not None:
             if randomize_bn:
-                st[bn + "/gamma"] = (0.5 + torch.rand(cout, generator=g)).numpy()
+                gam = 0.5 + torch.rand(cout, generator=g)
+                if tame and bn.endswith("branch2c"):
+                    gam = gam * 0.25
+                st[bn + "/gamma"] = gam.numpy()
                 st[bn + "/beta"] = (0.1 * torch.randn(cout, generator=g)).numpy()
                 st[bn + "/moving_mean"] = (0.1 * torch.randn(cout, generator=g)).numpy()
                 st[bn + "/moving_variance"] = (0.5 + torch.rand(cout, generator=g)).numpy()
