@@ -17,6 +17,7 @@
 // Epilogue: accumulators -> LDS (f32) -> whole-row 16-byte stores, with bias, residual
 // (identity or legacy-TF nearest upsample gather), ReLU / sigmoid fused.
 #include "rtn_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -34,6 +35,32 @@ __device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsi
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Buffer descriptor words in SGPRs (raw buffer, stride 0, range = `bytes`); every input is made wave-uniform.
+__device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_addr` (wave-uniform) + lane*16; lanes whose `voff` is outside
+// the descriptor range write zeros.  Issued from asm so that hipcc's waitcnt insertion does not see it (it would
+// drain it with vmcnt(0) before the next ds_read and lose the overlap with the MFMAs); the kernel waits for it itself
+// (dma_wait_all) before the barrier that publishes the buffer.  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void dma16_to_lds(const i32x4& srd, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct KGroup {
     const char* in;
@@ -81,6 +108,136 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& a, const uint4
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+    }
+}
+
+
+// ---- shared epilogue pieces.  A thread finishes 8 consecutive output channels of NIT output pixels; all residual
+// loads of those pixels are issued back-to-back BEFORE any of them is consumed (a load -> wait -> store chain per
+// row costs one HBM round trip per row: 25 % of the HBM-bound 1x1 layers' time when it was written that way).
+template <int ES>
+struct ResVec {
+    uint4 q[ES == 2 ? 1 : 2];
+};
+
+struct RowRef {
+    int b, cell;
+    bool valid;
+};
+
+__device__ __forceinline__ RowRef row_ref(int m, int M, int cells) {
+    RowRef r;
+    r.valid = m < M;
+    const int mc = r.valid ? m : M - 1;            // clamped: address math and loads stay unconditional
+    r.b = mc / cells;
+    r.cell = mc - r.b * cells;
+    return r;
+}
+
+// residual source pixel: identity, or tf.image.resize_images(NEAREST, align_corners=False):
+// src = min(floor(dst * in/out), in-1) with the ratio in float32 (model/layers.py:89-98)
+template <int ES>
+__device__ __forceinline__ const char* res_ptr(const KParams& p, const KGroup& G, const RowRef& r, int Wout, int n) {
+    long long rpix;
+    if (p.flags & RTN_CONV_RES_UPSAMPLE) {
+        const int oy = r.cell / Wout, ox = r.cell - oy * Wout;
+        int sy_ = (int)floorf((float)oy * G.rs_h);
+        int sx_ = (int)floorf((float)ox * G.rs_w);
+        sy_ = sy_ < G.Hres - 1 ? sy_ : G.Hres - 1;
+        sx_ = sx_ < G.Wres - 1 ? sx_ : G.Wres - 1;
+        rpix = (long long)sy_ * G.Wres + sx_;
+    } else {
+        rpix = r.cell;
+    }
+    return G.res + ((long long)r.b * G.res_img_stride + rpix * G.res_ld + n) * ES;
+}
+
+template <int ES>
+__device__ __forceinline__ void res_prefetch(const KParams& p, const KGroup& G, const RowRef& r, int Wout, int n, ResVec<ES>& out) {
+    const char* rp = res_ptr<ES>(p, G, r, Wout, n);
+    out.q[0] = *reinterpret_cast<const uint4*>(rp);
+    if constexpr (ES == 4) out.q[1] = *reinterpret_cast<const uint4*>(rp + 16);
+}
+
+__device__ __forceinline__ void load_bias8(const KParams& p, int n, float (&bv)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+}
+
+// bias -> residual -> ReLU / sigmoid -> bf16 or f32 store at the group's offsets.  `pre` is the prefetched residual
+// (used when res_vec), otherwise an unaligned / partial residual is read element-wise here.
+template <int ES>
+__device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup& G, const RowRef& r, int Wout, int n,
+                                                 float (&v)[8], const float (&bv)[8], bool res_vec, const ResVec<ES>& pre) {
+    if (!r.valid) return;
+    const int flags = p.flags;
+    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bv[j];
+    if (flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) {
+        if (res_vec) {
+            if constexpr (ES == 2) {
+                const unsigned w4[4] = {pre.q[0].x, pre.q[0].y, pre.q[0].z, pre.q[0].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] += __uint_as_float(w4[j] << 16);
+                    v[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                }
+            } else {
+                v[0] += __uint_as_float(pre.q[0].x); v[1] += __uint_as_float(pre.q[0].y);
+                v[2] += __uint_as_float(pre.q[0].z); v[3] += __uint_as_float(pre.q[0].w);
+                v[4] += __uint_as_float(pre.q[ES == 4 ? 1 : 0].x); v[5] += __uint_as_float(pre.q[ES == 4 ? 1 : 0].y);
+                v[6] += __uint_as_float(pre.q[ES == 4 ? 1 : 0].z); v[7] += __uint_as_float(pre.q[ES == 4 ? 1 : 0].w);
+            }
+        } else {
+            const char* rp = res_ptr<ES>(p, G, r, Wout, n);
+            for (int j = 0; j < nvalid; ++j) {
+                if constexpr (ES == 2)
+                    v[j] += __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(rp)[j]) << 16);
+                else
+                    v[j] += reinterpret_cast<const float*>(rp)[j];
+            }
+        }
+    }
+    if (flags & RTN_CONV_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    if (flags & RTN_CONV_SIGMOID) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
+    }
+    const long long oidx = (long long)r.b * G.out_img_stride + G.out_off + (long long)r.cell * p.out_ld + n;
+    const bool out_f32 = (ES == 4) || (flags & RTN_CONV_OUT_F32);
+    if (out_f32) {
+        float* op = reinterpret_cast<float*>(G.out) + oidx;
+        if (p.vec_ok) {
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) op[j] = v[j];
+        }
+    } else {
+        unsigned short* op = reinterpret_cast<unsigned short*>(G.out) + oidx;
+        if (p.vec_ok) {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]);
+            o.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4*>(op) = o;
+        } else {
+            for (int j = 0; j < nvalid; ++j) {
+                const __bf16 hb = (__bf16)v[j];
+                op[j] = __builtin_bit_cast(unsigned short, hb);
+            }
+        }
     }
 }
 
@@ -218,17 +375,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
     RTN_LOAD_TILE(0);
     RTN_STORE_TILE(0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        // even step: compute buffer 0 while the loads of step kt+1 fly, then stage them into buffer 1
-        if (kt + 1 < nkt) RTN_LOAD_TILE(kt + 1);
-        RTN_COMPUTE_TILE(0);
-        if (kt + 1 < nkt) RTN_STORE_TILE(1);
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        // compute buffer `cur` while the loads of step kt+1 fly, then stage them into the other buffer
+        const bool more = kt + 1 < nkt;
+        if (more) RTN_LOAD_TILE(kt + 1);
+        RTN_COMPUTE_TILE(cur);
+        if (more) RTN_STORE_TILE(cur ^ 1);
         __syncthreads();
-        if (kt + 1 >= nkt) break;
-        if (kt + 2 < nkt) RTN_LOAD_TILE(kt + 2);
-        RTN_COMPUTE_TILE(1);
-        if (kt + 2 < nkt) RTN_STORE_TILE(0);
-        __syncthreads();
+        cur ^= 1;
     }
 #undef RTN_LOAD_TILE
 #undef RTN_STORE_TILE
@@ -245,104 +401,250 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
                 S[(wm * 64 + i * 16 + kq * 4 + r) * SLD + wn * WN + j * 16 + lrow] = acc[i][j][r];
     __syncthreads();
 
-    constexpr int TPR = BN / 8, RPP = NT / TPR;
+    constexpr int TPR = BN / 8, RPP = NT / TPR, NIT = BM / RPP;
     const int ecol = (t % TPR) * 8;
     const int n = n0 + ecol;
     if (n >= p.N) return;
-    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-    const int flags = p.flags;
-    const bool out_f32 = (ES == 4) || (flags & RTN_CONV_OUT_F32);
+    const bool res_vec = (p.flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) && p.vec_ok;
     float bv[8];
+    load_bias8(p, n, bv);
+    RowRef rows[NIT];
+    ResVec<ES> pre[NIT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-    if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
-        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    for (int it = 0; it < NIT; ++it) {
+        rows[it] = row_ref(m0 + t / TPR + it * RPP, M, cells);
+        if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, n, pre[it]);
     }
-    for (int row = t / TPR; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= M) break;
-        const int b = m / cells;
-        const int cell = m - b * cells;
-        const float* s = S + row * SLD + ecol;
-        const float4 v0 = *reinterpret_cast<const float4*>(s);
-        const float4 v1 = *reinterpret_cast<const float4*>(s + 4);
-        float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
-                      v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-        if (flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) {
-            long long rpix;
-            if (flags & RTN_CONV_RES_UPSAMPLE) {
-                // tf.image.resize_images(NEAREST, align_corners=False): src = min(floor(dst*in/out), in-1), f32
-                const int oy = cell / Wout, ox = cell - oy * Wout;
-                int sy_ = (int)floorf((float)oy * G.rs_h);
-                int sx_ = (int)floorf((float)ox * G.rs_w);
-                sy_ = sy_ < G.Hres - 1 ? sy_ : G.Hres - 1;
-                sx_ = sx_ < G.Wres - 1 ? sx_ : G.Wres - 1;
-                rpix = (long long)sy_ * G.Wres + sx_;
-            } else {
-                rpix = cell;
-            }
-            const char* rp = G.res + ((long long)b * G.res_img_stride + rpix * G.res_ld + n) * ES;
-            if (p.vec_ok) {
-                if constexpr (ES == 2) {
-                    const uint4 rr = *reinterpret_cast<const uint4*>(rp);
-                    const unsigned w4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[2 * j] += __uint_as_float(w4[j] << 16);
-                        v[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
-                    }
-                } else {
-                    const float4 r0v = *reinterpret_cast<const float4*>(rp);
-                    const float4 r1v = *reinterpret_cast<const float4*>(rp + 16);
-                    v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
-                    v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
-                }
-            } else {
-                for (int j = 0; j < nvalid; ++j) {
-                    if constexpr (ES == 2)
-                        v[j] += __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(rp)[j]) << 16);
-                    else
-                        v[j] += reinterpret_cast<const float*>(rp)[j];
-                }
-            }
-        }
-        if (flags & RTN_CONV_RELU) {
+    for (int it = 0; it < NIT; ++it) {
+        const float* sp = S + (t / TPR + it * RPP) * SLD + ecol;
+        const float4 v0 = *reinterpret_cast<const float4*>(sp);
+        const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second generation, for the compute-bound layers: 256 (M) x BN (64|128|256) tile, 512 threads = 8 waves in 4x2, wave
+// tile 64 x BN/2.  Both operands are staged by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows x 128 B per
+// wave-instruction): no staging VGPRs, no ds_write pass.  The LDS image is lane-linear, so the XOR swizzle sits on the
+// per-lane SOURCE chunk (same 128-byte line: coalescing unchanged) and on the fragment reads (cdna guide, rule 21).
+// Out-of-image taps still get OOB_OFFSET: the range check makes the DMA write zeros.  One barrier per K step: stage
+// step k+1 into the other buffer, MFMA step k, vmcnt(0)+barrier.  Epilogue is wave-private (no block barrier): each wave
+// moves its 64 x BN/2 accumulators through its own LDS slice, 32 rows at a time, and stores whole rows.
+constexpr int BM2 = 256;
+constexpr int NT2 = 512;
+
+template <int ES, int BN, bool IL>
+__global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
+    constexpr int ESH = (ES == 2) ? 1 : 2;
+    constexpr int WN = BN / 2;
+    constexpr int NI = WN / 16;
+    constexpr int MI = 4;
+    constexpr int NBI = BN / 64;                 // B row-blocks (8 rows) staged per wave
+    constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
+    constexpr int SLDW = WN + 4;
+    constexpr int EPI_WAVE_BYTES = 32 * SLDW * 4;
+    constexpr int EPI_BYTES = 8 * EPI_WAVE_BYTES;
+    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mtile_g = wg / p.ntiles_n;
+    const int ntile = wg - mtile_g * p.ntiles_n;
+    int gi = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-        }
-        if (flags & RTN_CONV_SIGMOID) {
+    for (int i = 1; i < RTN_MAX_GROUPS; ++i)
+        if (i < p.ngroups && mtile_g >= p.g[i].tile_begin) gi = i;
+    const KGroup& G = p.g[gi];
+    const int m0 = (mtile_g - G.tile_begin) * BM2;
+    const int n0 = ntile * BN;
+    const int M = G.M;
+    const int Wout = G.Wout;
+    const int cells = G.Hout * Wout;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = lane >> 3;                         // row inside an 8-row block
+    const int c = (lane & 7) ^ lr;                    // global 16-byte chunk this lane fetches (swizzle on the source)
+
+    const i32x4 in_srd = make_srd(G.in, G.in_bytes);
+    const i32x4 w_srd = make_srd(p.w, p.w_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned rowbase[4];
+    int iy0[4], ix0[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
-        }
-        const long long oidx = (long long)b * G.out_img_stride + G.out_off + (long long)cell * p.out_ld + n;
-        if (out_f32) {
-            float* op = reinterpret_cast<float*>(G.out) + oidx;
-            if (p.vec_ok) {
-                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-                for (int j = 0; j < nvalid; ++j) op[j] = v[j];
-            }
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (i * 8 + wave) * 8 + lr;
+        if (m < M) {
+            const int b = m / cells;
+            const int rem = m - b * cells;
+            const int oy = rem / Wout;
+            const int ox = rem - oy * Wout;
+            iy0[i] = oy * p.sy - p.pad_t;
+            ix0[i] = ox * p.sx - p.pad_l;
+            rowbase[i] = (unsigned)((long long)b * G.in_img_stride_b + (long long)iy0[i] * G.in_row_stride_b +
+                                    (long long)ix0[i] * p.pix_stride_b);
         } else {
-            unsigned short* op = reinterpret_cast<unsigned short*>(G.out) + oidx;
-            if (p.vec_ok) {
-                uint4 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                o.z = pack_bf16x2(v[4], v[5]);
-                o.w = pack_bf16x2(v[6], v[7]);
-                *reinterpret_cast<uint4*>(op) = o;
-            } else {
-                for (int j = 0; j < nvalid; ++j) {
-                    const __bf16 hb = (__bf16)v[j];
-                    op[j] = __builtin_bit_cast(unsigned short, hb);
+            iy0[i] = -(1 << 28);
+            ix0[i] = 0;
+            rowbase[i] = 0;
+        }
+    }
+    // B rows beyond w_rows fall outside the weight descriptor and read as zeros
+    const unsigned wbase = (unsigned)(n0 + wave * 8 + lr) * (unsigned)p.Kbytes + (unsigned)c * 16u;
+    const unsigned wstep = 64u * (unsigned)p.Kbytes;
+    const int Hin = G.Hin, Win = G.Win, in_row_stride_b = G.in_row_stride_b;
+
+    // One staging piece (1 KiB per wave): D < 4 -> A row-block D of this wave, else B row-block D-4.
+#define RTN_TAPS(KT)                                                                                                \
+    const int kb_ = (KT) * 128 + c * 16;                                                                            \
+    const int k0_ = kb_ >> ESH;                                                                                     \
+    const int kpos_ = k0_ >> p.cshift;                                                                              \
+    const int coff_ = k0_ & p.crun_mask;                                                                            \
+    const int kh_ = (kpos_ * p.kw_inv) >> 16;                                                                       \
+    const int kw_ = kpos_ - kh_ * p.KW;                                                                             \
+    const unsigned delta_ = (unsigned)(kh_ * in_row_stride_b + kw_ * p.pix_stride_b + coff_ * ES);                  \
+    const unsigned wk_ = wbase + (unsigned)(KT) * 128u;
+#define RTN_DMA(BUF, D)                                                                                             \
+    {                                                                                                               \
+        if ((D) < 4) {                                                                                              \
+            const int iy_ = iy0[(D) & 3] + kh_, ix_ = ix0[(D) & 3] + kw_;                                           \
+            const bool ok_ = (unsigned)iy_ < (unsigned)Hin && (unsigned)ix_ < (unsigned)Win;                        \
+            dma16_to_lds(in_srd, ok_ ? rowbase[(D) & 3] + delta_ : OOB_OFFSET,                                      \
+                         lds_base + (unsigned)((BUF) * A_BYTES + wave * 1024 + ((D) & 3) * 8192));                  \
+        } else {                                                                                                    \
+            dma16_to_lds(w_srd, wk_ + (unsigned)((D) - 4) * wstep,                                                  \
+                         lds_base + (unsigned)(2 * A_BYTES + (BUF) * B_BYTES + wave * 1024 + ((D) - 4) * 8192));    \
+        }                                                                                                           \
+    }
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int rd0 = ((kq ^ (lrow & 7)) << 4);
+    const int rd1 = (((4 + kq) ^ (lrow & 7)) << 4);
+    const int a_row_off = (wm * 64 + lrow) * 128;
+    const int b_row_off = (wn * WN + lrow) * 128;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NJ = NI < 4 ? NI : 4;           // B fragments held at once
+    constexpr int ND = 4 + NBI;                   // staging pieces per wave per K step
+    constexpr int NS = 2 * (NI / NJ) * 2;         // MFMA groups per K step = slots the pieces are spread over
+
+    const int nkt = p.nkt;
+    {
+        RTN_TAPS(0);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) RTN_DMA(0, d);
+    }
+    dma_wait_all();
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        RTN_TAPS(kt + 1);
+        const char* A_ = lds + cur * A_BYTES + a_row_off;
+        const char* B_ = lds + 2 * A_BYTES + cur * B_BYTES + b_row_off;
+        if (!IL && more) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) RTN_DMA(cur ^ 1, d);
+        }
+        // MFMAs of step kt with the DMA issues of step kt+1 interleaved between the MFMA groups: the matrix pipe
+        // keeps running while this wave issues its staging pieces (both waves of a SIMD run this in lockstep).
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rd = ks ? rd1 : rd0;
+            uint4 a_[MI];
+#pragma unroll
+            for (int i_ = 0; i_ < MI; ++i_) a_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rd);
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += NJ) {
+                uint4 b_[NJ];
+#pragma unroll
+                for (int j_ = 0; j_ < NJ; ++j_) b_[j_] = *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rd);
+#pragma unroll
+                for (int ih = 0; ih < 2; ++ih) {
+#pragma unroll
+                    for (int i_ = 2 * ih; i_ < 2 * ih + 2; ++i_)
+#pragma unroll
+                        for (int j_ = 0; j_ < NJ; ++j_) mma_step<ES>(acc[i_][jh + j_], a_[i_], b_[j_]);
+                    const int slot = (ks * (NI / NJ) + jh / NJ) * 2 + ih;
+                    if (IL && more) {
+#pragma unroll
+                        for (int d = slot * ND / NS; d < (slot + 1) * ND / NS; ++d) RTN_DMA(cur ^ 1, d);
+                    }
                 }
             }
         }
+        dma_wait_all();                                     // this wave's pieces of step kt+1 have landed ...
+        __syncthreads();                                    // ... and so have everyone else's; buffer `cur` is free
+        cur ^= 1;
     }
+#undef RTN_TAPS
+#undef RTN_DMA
+
+    // ---- wave-private epilogue: 2 halves of 32 rows through this wave's LDS slice
+    float* S = reinterpret_cast<float*>(lds + wave * EPI_WAVE_BYTES);
+    constexpr int TPRW = WN / 8, RPPW = 64 / TPRW, NITW = 32 / RPPW;
+    const int ecol = (lane % TPRW) * 8;
+    const int n = n0 + wn * WN + ecol;
+    const bool ncol_ok = n < p.N;
+    const bool res_vec = (p.flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) && p.vec_ok;
+    float bv[8];
+    load_bias8(p, ncol_ok ? n : 0, bv);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        RowRef rows[NITW];
+        ResVec<ES> pre[NITW];
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            rows[it] = row_ref(m0 + wm * 64 + hh * 32 + lane / TPRW + it * RPPW, M, cells);
+            rows[it].valid = rows[it].valid && ncol_ok;
+            if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, ncol_ok ? n : 0, pre[it]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(i * 16 + kq * 4 + r) * SLDW + j * 16 + lrow] = acc[hh * 2 + i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's LDS writes have landed
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            const float* sp = S + (lane / TPRW + it * RPPW) * SLDW + ecol;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp);
+            const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // reads done before the next half overwrites the slice
+    }
+}
+
+// Tuning knobs, read on every call so one process can A/B them: RTN_CONV_IMPL=1|2 forces a kernel generation
+// (unset/0 = heuristic); RTN_CONV_IL=1 interleaves the staging DMA issues between MFMA groups
+// instead of issuing them ahead of the MFMA block (measured slower: 1084 vs 1226 TF/s on the head layers).
+int rtn_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+int rtn_conv_impl_override() {
+    const int v = rtn_env_int("RTN_CONV_IMPL", 0);
+    return (v == 1 || v == 2) ? v : 0;
 }
 
 int ilog2_exact(int v) {
@@ -386,6 +688,19 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
     memset(&p, 0, sizeof(p));
     bool vec_ok = (d->N % 8 == 0) && (d->out_ld % 8 == 0);
     long long mtiles = 0;
+    // ---- kernel generation: 2 = 256-row LDS-DMA kernel (compute-bound layers), 1 = 128-row register-staged kernel.
+    long long Mtot = 0;
+    for (int i = 0; i < d->ngroups; ++i) Mtot += (long long)d->g[i].Hout * d->g[i].Wout * d->batch;
+    int impl = rtn_conv_impl_override();
+    if (impl == 0) {
+        // measured on MI355X (tools/ab_conv.py, same-process A/B): the 256-row kernel wins once its grid fills the
+        // 256 CUs (one workgroup per CU) and the K loop is long enough to amortise its prologue; the 128-row kernel
+        // (2 workgroups/CU) wins on small-M layers (res5*, P5..P7) and on the 1-2 step HBM-bound 1x1 layers.
+        const int bn2 = d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256);
+        const long long blocks2 = ((Mtot + BM2 - 1) / BM2) * ((d->N + bn2 - 1) / bn2);
+        impl = ((Ktot * es) >= 1024 && blocks2 >= 200 && d->N != 128) ? 2 : 1;
+    }
+    const int TM = impl == 2 ? BM2 : BM;
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
         KGroup& g = p.g[i];
@@ -430,10 +745,10 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         g.rs_w = s.Wout > 0 ? (float)s.Wres / (float)s.Wout : 0.f;
         g.M = (int)M;
         g.tile_begin = (int)mtiles;
-        mtiles += (M + BM - 1) / BM;
+        mtiles += (M + TM - 1) / TM;
     }
     (void)out_f32;
-    const int BN = d->N <= 64 ? 64 : 128;
+    const int BN = impl == 2 ? (d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256)) : (d->N <= 64 ? 64 : 128);
     p.w = (const char*)d->w;
     p.bias = d->bias;
     if ((long long)d->w_rows * Ktot * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "conv: weights exceed the 4 GiB buffer-descriptor range");
@@ -459,13 +774,27 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
     const long long grid = mtiles * p.ntiles_n;
     if (grid < 1 || grid > 0x7fffffffll) return rtn_fail(h, RTN_EINVAL, "conv: grid %lld", grid);
 
-    dim3 gdim((unsigned)grid), bdim(NT);
-    if (es == 2) {
-        if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<2, 64>), gdim, bdim, 0, h->stream, p);
-        else          hipLaunchKernelGGL((conv_igemm_kernel<2, 128>), gdim, bdim, 0, h->stream, p);
+    dim3 gdim((unsigned)grid);
+    if (impl == 2) {
+        dim3 bdim(NT2);
+        const bool il = rtn_env_int("RTN_CONV_IL", 0) != 0;
+#define RTN_L2(E, B)                                                                                     \
+    do {                                                                                                 \
+        if (il) hipLaunchKernelGGL((conv_igemm2_kernel<E, B, true>), gdim, bdim, 0, h->stream, p);       \
+        else    hipLaunchKernelGGL((conv_igemm2_kernel<E, B, false>), gdim, bdim, 0, h->stream, p);      \
+    } while (0)
+        if (es == 2) { if (BN == 64) RTN_L2(2, 64); else if (BN == 128) RTN_L2(2, 128); else RTN_L2(2, 256); }
+        else         { if (BN == 64) RTN_L2(4, 64); else if (BN == 128) RTN_L2(4, 128); else RTN_L2(4, 256); }
+#undef RTN_L2
     } else {
-        if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<4, 64>), gdim, bdim, 0, h->stream, p);
-        else          hipLaunchKernelGGL((conv_igemm_kernel<4, 128>), gdim, bdim, 0, h->stream, p);
+        dim3 bdim(NT);
+        if (es == 2) {
+            if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<2, 64>), gdim, bdim, 0, h->stream, p);
+            else          hipLaunchKernelGGL((conv_igemm_kernel<2, 128>), gdim, bdim, 0, h->stream, p);
+        } else {
+            if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<4, 64>), gdim, bdim, 0, h->stream, p);
+            else          hipLaunchKernelGGL((conv_igemm_kernel<4, 128>), gdim, bdim, 0, h->stream, p);
+        }
     }
     RTN_CHECK_LAUNCH(h, "conv_igemm_kernel");
     return RTN_OK;
