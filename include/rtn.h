@@ -68,6 +68,10 @@ const char* rtn_version(void);
                                        UpsampleLike + Add, model/layers.py:89-98,
                                        model/defineModel.py:184,189-190,195                */
 #define RTN_CONV_OUT_F32      0x10  /* store f32 even when dtype is bf16                   */
+#define RTN_CONV_RELU_MASK    0x20  /* backward of a ReLU: result = mask[b,oy,ox,n] > 0 ? result : 0, applied after
+                                       the residual add (the residual carries the other gradient contributions) */
+#define RTN_CONV_MASK_PRE     0x40  /* with RELU_MASK: mask the convolution result BEFORE the residual add (C6_relu:
+                                       the residual holds gradients of the un-rectified tensor)            */
 
 typedef struct {
     const void* in;          /* NHWC activations                                       */
@@ -87,6 +91,17 @@ typedef struct {
     int32_t Hout, Wout;
     int32_t Hres, Wres;      /* residual map extent (RES_UPSAMPLE)                     */
     int32_t res_ld;          /* elements per pixel of `res`                            */
+    const void* mask;        /* RELU_MASK: the forward activation whose ReLU is being
+                                differentiated; indexed like `out` (mask_ld per pixel)  */
+    int64_t mask_elems;
+    int64_t mask_img_stride;
+    int32_t mask_ld;
+    int32_t out_step;        /* 0/1 = dense; s > 1 scatters output pixel (oy,ox) to pixel
+                                (oy*s, ox*s) of an image out_pix_w pixels wide: the
+                                data gradient of a stride-s 1x1 'valid' convolution
+                                (caller zero-fills `out`); res/mask use the same pixel  */
+    int32_t out_pix_w;       /* width in pixels of the `out` image when out_step > 1   */
+    int32_t reserved_;
 } rtn_conv_group_t;
 
 typedef struct {
@@ -112,6 +127,47 @@ typedef struct {
 } rtn_conv_desc_t;
 
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
+
+/* Data gradient (what TF autodiff emits as Conv2DBackpropInput under fit_generator, RetinaNet.py:280).  The same
+ * implicit GEMM run on dY: `in` = dY, `w` = the forward weights re-packed by rtn_pack_dgrad_weights
+ * (w_d[c][(KH-1-kh, KW-1-kw, n)] = w[n][(kh,kw,c)]), pad = K-1-pad_fwd, stride 1 (a stride-2 1x1 forward conv uses
+ * out_step = 2; a stride-2 3x3 forward conv is differentiated on the zero-inserted dY built by rtn_zero_insert2).
+ * RES_SAME accumulates into an existing gradient, RELU_MASK applies the ReLU of the tensor being differentiated. */
+int rtn_conv2d_dgrad(rtn_handle_t h, const rtn_conv_desc_t* d);
+int rtn_pack_dgrad_weights(rtn_handle_t h, const void* w_fwd, void* w_dgrad, int dtype, int N, int w_rows_fwd,
+                           int KH, int KW, int Cin, int Cout_run, int w_rows_dgrad);
+
+/* Weight gradient (Conv2DBackpropFilter).  `d` describes the FORWARD convolution with two re-interpretations:
+ * g[i].out / out_elems / out_img_stride / out_off and out_ld describe dY (same dtype as `in`; N and out_ld must span whole
+ * 16-byte chunks — the head outputs' 36- and 9-channel gradients are padded to 64 channels with rtn_pad_cast_rows), and
+ * w / bias are ignored.  dW is f32 [w_rows][KH*KW*Crun] in the forward weight layout and is ACCUMULATED into (zero it
+ * once per step; the five pyramid levels and any number of micro-batches add into the same buffer).  */
+size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d);
+int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes);
+/* db[n] += sum over rows of dy[row][n]   (rows x N matrix with leading dimension ld, dtype bf16/f32) */
+int rtn_bias_grad(rtn_handle_t h, const void* dy, int dtype, int64_t rows, int N, int64_t ld, float* db);
+/* out[r][0..cout) = cast(in[r][0..cin)), zero beyond cin */
+int rtn_pad_cast_rows(rtn_handle_t h, const float* in, void* out, int dtype, int64_t rows, int cin, int cout);
+/* out[b][2y][2x] = in[b][y][x], zero elsewhere; out is [B][Hu][Wu][C] with Hu >= 2H-1, Wu >= 2W-1 */
+int rtn_zero_insert2(rtn_handle_t h, const void* in, void* out, int dtype, int B, int H, int W, int C, int Hu, int Wu);
+/* adjoint of UpsampleLike+Add (model/layers.py:89-98): d_src[sy][sx] (+)= sum of d_dst over the pixels that read it */
+int rtn_upsample_add_bwd(rtn_handle_t h, const void* d_dst, void* d_src, int dtype, int B, int Hd, int Wd, int Hs, int Ws,
+                         int C, int accumulate);
+/* keras_resnet pool1 backward; scratch_f32 holds B*Hin*Win*C floats */
+int rtn_maxpool3x3s2_tfsame_bwd(rtn_handle_t h, const void* x, const void* dy, void* dx, int dtype, int B, int Hin, int Win,
+                                int C, float* scratch_f32, int relu_mask /* also zero dx where x <= 0 (x is a ReLU output) */);
+
+/* ---- optimizer: Adam(lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=0.001)  (RetinaNet.py:130) ---------------
+ * Parameters live in ONE flat f32 buffer (forward weight layout per layer).  gscale[i] multiplies the raw gradient
+ * (frozen-BN fold factor of the layer's output channel; 0 for structurally-zero slots), fold[i] re-creates the forward
+ * weight w_fwd[i] = cast(w[i] * fold[i]).  Clipping is by the GLOBAL norm of all gradients (standalone Keras 2.x,
+ * SURVEY §8a a20): sumsq = sum((g*gscale)^2) from rtn_sumsq (all-reduced by the caller under data parallelism),
+ * factor = min(1, clipnorm / (sqrt(sumsq) * |grad_mul|)); grad_mul rescales g (e.g. 1/world_size).  clipnorm <= 0: off. */
+size_t rtn_sumsq_workspace_bytes(void);
+int rtn_sumsq(rtn_handle_t h, const float* g, const float* scale, int64_t n, double* out, void* workspace, size_t workspace_bytes);
+int rtn_adam_clipnorm_step(rtn_handle_t h, float* w, float* m, float* v, const float* g, const float* gscale, const float* fold,
+                           void* w_fwd, int fwd_dtype, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                           const double* sumsq, float clipnorm, float grad_mul);
 
 /* ---- stem input packing ------------------------------------------------------------
  * NHWC C=3 image batch -> zero-padded [B][Hp][Wp][4] so that the 7x7/2 stem conv
@@ -189,6 +245,15 @@ int rtn_retina_loss_bwd(rtn_handle_t h, int64_t rows, int num_classes,
                         float alpha, float gamma, float sigma,
                         float inv_norm_cls, float inv_norm_reg, int wrt_logits,
                         float* d_cls, float* d_reg);
+
+/* Same as rtn_retina_loss_bwd with the normalisers read on the device: inv_norm = 1 / max(1, sums[2]) for the focal
+ * term and 1 / max(1, sums[3]) for smooth-L1, `sums` being rtn_retina_loss_fwd's output (all-reduced over ranks first
+ * under data parallelism) — no host round trip between loss forward and backward. */
+int rtn_retina_loss_bwd_dev(rtn_handle_t h, int64_t rows, int num_classes,
+                            const float* labels_batch, const float* regression_batch,
+                            const float* classification, const float* regression,
+                            float alpha, float gamma, float sigma, const double* sums, int wrt_logits,
+                            float* d_cls, float* d_reg);
 
 /* ---- decode + clip + score threshold + NMS + top-k + pad ---------------------------
  * Replaces Anchors/RegressBoxes/ClipBoxes/FilterDetections for num_classes = K with

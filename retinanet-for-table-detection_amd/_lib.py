@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "librtn.so")
 RTN_BF16, RTN_F32, RTN_U8 = 0, 1, 2
 RTN_MAX_GROUPS, RTN_MAX_GT, RTN_MAX_DET = 5, 64, 300
 
-CONV_RELU, CONV_SIGMOID, CONV_RES_SAME, CONV_RES_UPSAMPLE, CONV_OUT_F32 = 0x01, 0x02, 0x04, 0x08, 0x10
+CONV_RELU, CONV_SIGMOID, CONV_RES_SAME, CONV_RES_UPSAMPLE, CONV_OUT_F32, CONV_RELU_MASK, CONV_MASK_PRE = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
 
 ERRNAMES = {0: "RTN_OK", -1: "RTN_EINVAL", -2: "RTN_EHIP", -3: "RTN_ENOMEM", -4: "RTN_EBOUNDS"}
 
@@ -32,6 +32,8 @@ class ConvGroup(C.Structure):
         ("in_row_stride", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
         ("Hout", C.c_int32), ("Wout", C.c_int32), ("Hres", C.c_int32), ("Wres", C.c_int32),
         ("res_ld", C.c_int32),
+        ("mask", C.c_void_p), ("mask_elems", C.c_int64), ("mask_img_stride", C.c_int64),
+        ("mask_ld", C.c_int32), ("out_step", C.c_int32), ("out_pix_w", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -65,6 +67,18 @@ SIGNATURES = {
     "rtn_last_error": (C.c_char_p, [_P]),
     "rtn_version": (C.c_char_p, []),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
+    "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
+    "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "rtn_conv2d_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
+    "rtn_conv2d_wgrad": (_I, [_P, C.POINTER(ConvDesc), _P, _P, _SZ]),
+    "rtn_bias_grad": (_I, [_P, _P, _I, _I64, _I, _I64, _P]),
+    "rtn_pad_cast_rows": (_I, [_P, _P, _P, _I, _I64, _I, _I]),
+    "rtn_zero_insert2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "rtn_upsample_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "rtn_maxpool3x3s2_tfsame_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
+    "rtn_sumsq_workspace_bytes": (_SZ, []),
+    "rtn_sumsq": (_I, [_P, _P, _P, _I64, _P, _P, _SZ]),
+    "rtn_adam_clipnorm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _F, _F, _F, _F, _P, _F, _F]),
     "rtn_stem_pack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I]),
     "rtn_maxpool3x3s2_tfsame_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "rtn_relu": (_I, [_P, _P, _P, _I, _I64]),
@@ -75,6 +89,7 @@ SIGNATURES = {
     "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
     "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),
     "rtn_retina_loss_bwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P]),
+    "rtn_retina_loss_bwd_dev": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P]),
     "rtn_detect_workspace_bytes": (_SZ, [_I, _I64, _I]),
     "rtn_decode_filter_nms": (_I, [_P, C.POINTER(AnchorCfg), _I, _I, _P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _SZ]),
 }

@@ -1,0 +1,719 @@
+// rtn_backward.hip — the backward / optimizer half of the training step (RetinaNet.py:125-131,280: Keras compile +
+// fit_generator => TF autodiff of every conv, Adam(lr, clipnorm=0.001)).
+//
+//   rtn_conv2d_wgrad      dW[n][(kh,kw,c)] += sum_pixels dY[pix][n] * X[tap(pix,kh,kw)][c]   (Conv2DBackpropFilter)
+//   rtn_bias_grad         db[n] += sum_pixels dY[pix][n]
+//   rtn_zero_insert2      dY -> zero-inserted dY for the data gradient of the stride-2 3x3 convs (P6, P7)
+//   rtn_upsample_add_bwd  adjoint of UpsampleLike (legacy-TF nearest) + Add  (model/layers.py:89-98)
+//   rtn_maxpool3x3s2_tfsame_bwd
+//   rtn_sumsq / rtn_adam_clipnorm_step   global-norm clip + Adam on the flat parameter buffer
+//
+// wgrad on MFMA: the reduction runs over PIXELS, so both operands are needed pixel-major per lane while memory is
+// channel-major.  Tiles [64 pixels][16 x 16-byte chunks] are staged as they lie in memory (range-checked buffer loads:
+// padding taps and tail pixels read zeros) and the fragments are read TRANSPOSED with ds_read_b64_tr_b16 (gfx950): one
+// read hands a lane 4 consecutive pixels of its channel.  Rows are padded to 288 B and rows 8..15 of every 16 swap
+// their 128-byte halves, which makes the transposed reads of a 32-lane half conflict-free.  The pixel range is split
+// over gridDim.y; partial tiles are added into the f32 gradient with global_atomic_add_f32.
+#include "rtn_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
+constexpr int WG_ROWB = 288;                 // LDS bytes per pixel row (256 B of channels + 32 B pad)
+constexpr int WG_TILE_B = 64 * WG_ROWB;      // one operand tile
+
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+struct WGroup {
+    const char* x;
+    const char* dy;
+    unsigned x_bytes, dy_bytes;
+    long long x_img_stride_b, dy_img_stride_b, dy_off_b;
+    int x_row_stride_b;
+    int Hin, Win, Hout, Wout;
+    int M;
+    int tile_begin;      // first 64-pixel tile of the group
+};
+
+struct WParams {
+    WGroup g[RTN_MAX_GROUPS];
+    float* dW;
+    const uint4* rowinfo;
+    int ngroups, total_tiles, tiles_per_split, ntiles_k;
+    int N, Ktot;
+    int cshift, crun_mask, kw_inv, KW;
+    int pix_stride_b, sy, sx, pad_t, pad_l, dy_ld_b;
+};
+
+// per output pixel: {byte offset of tap (0,0) in X (mod 2^32), byte offset of the dY row, iy0 | ix0 << 16, -}
+template <int ES>
+__global__ __launch_bounds__(256) void wgrad_rowinfo_kernel(const WParams p, uint4* __restrict__ info) {
+    const long long total = (long long)p.total_tiles * 64;
+    for (long long R = (long long)blockIdx.x * blockDim.x + threadIdx.x; R < total; R += (long long)gridDim.x * blockDim.x) {
+        const int tile = (int)(R >> 6);
+        int gi = 0;
+        for (int i = 1; i < RTN_MAX_GROUPS; ++i)
+            if (i < p.ngroups && tile >= p.g[i].tile_begin) gi = i;
+        const WGroup& G = p.g[gi];
+        const int m = (int)(R - (long long)G.tile_begin * 64);
+        uint4 o = make_uint4(0u, OOB_OFFSET, 0x00008000u, 0u);          // iy0 = -32768: every tap out of range
+        if (m < G.M) {
+            const int cells = G.Hout * G.Wout;
+            const int b = m / cells;
+            const int cell = m - b * cells;
+            const int oy = cell / G.Wout, ox = cell - oy * G.Wout;
+            const int iy0 = oy * p.sy - p.pad_t, ix0 = ox * p.sx - p.pad_l;
+            o.x = (unsigned)((long long)b * G.x_img_stride_b + (long long)iy0 * G.x_row_stride_b + (long long)ix0 * p.pix_stride_b);
+            o.y = (unsigned)((long long)b * G.dy_img_stride_b + G.dy_off_b + (long long)cell * p.dy_ld_b);
+            o.z = ((unsigned)iy0 & 0xffffu) | ((unsigned)ix0 << 16);
+        }
+        info[R] = o;
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
+    constexpr int CE = 16 / ES;                // elements per 16-byte chunk
+    constexpr int CH = 16 * CE;                // channels per tile side: 128 (bf16) / 64 (f32)
+    constexpr int WT = CH / 2;                 // per-wave extent
+    constexpr int FI = WT / 16;                // 16x16 MFMA tiles per wave side: 4 / 2
+    __shared__ __attribute__((aligned(16))) char lds[4 * WG_TILE_B];   // [buf][dY | X]
+
+    const int tile_n = blockIdx.x / p.ntiles_k;
+    const int tile_k = blockIdx.x - tile_n * p.ntiles_k;
+    const int n0 = tile_n * CH, k0 = tile_k * CH;
+    const int tlo = blockIdx.y * p.tiles_per_split;
+    int thi = tlo + p.tiles_per_split;
+    thi = thi < p.total_tiles ? thi : p.total_tiles;
+    if (tlo >= thi) return;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ch = t & 15, r0 = t >> 4;
+    const int st_off = r0 * WG_ROWB + ((ch ^ (((r0 >> 3) & 1) << 3)) << 4);
+
+    // this thread's X chunk: fixed tap and channel offset for the whole kernel
+    const int kk = k0 + ch * CE;
+    const bool kvalid = kk < p.Ktot;
+    const int kpos = kk >> p.cshift;
+    const int coff = kk & p.crun_mask;
+    const int kh = (kpos * p.kw_inv) >> 16;
+    const int kw = kpos - kh * p.KW;
+    const int nn = n0 + ch * CE;
+    const bool nvalid = nn < p.N;
+    const unsigned dyo = (unsigned)(nn * ES);
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[FI][FI];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+#define WG_LOAD(TILE)                                                                                               \
+    {                                                                                                               \
+        int gi_ = 0;                                                                                                \
+        _Pragma("unroll") for (int i_ = 1; i_ < RTN_MAX_GROUPS; ++i_)                                               \
+            if (i_ < p.ngroups && (TILE) >= p.g[i_].tile_begin) gi_ = i_;                                           \
+        const WGroup& G_ = p.g[gi_];                                                                                \
+        const __amdgpu_buffer_rsrc_t xs_ = __builtin_amdgcn_make_buffer_rsrc(                                       \
+            (void*)G_.x, 0, (int)__builtin_amdgcn_readfirstlane((int)G_.x_bytes), 0x00020000);                      \
+        const __amdgpu_buffer_rsrc_t ys_ = __builtin_amdgcn_make_buffer_rsrc(                                       \
+            (void*)G_.dy, 0, (int)__builtin_amdgcn_readfirstlane((int)G_.dy_bytes), 0x00020000);                    \
+        const unsigned delta_ = (unsigned)(kh * G_.x_row_stride_b + kw * p.pix_stride_b + coff * ES);               \
+        const int Hin_ = G_.Hin, Win_ = G_.Win;                                                                     \
+        uint4 ri_[4];                                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ri_[i_] = p.rowinfo[(long long)(TILE) * 64 + r0 + 16 * i_]; \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+            const int iy_ = (int)(short)(ri_[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri_[i_].z >> 16) + kw;       \
+            const bool ok_ = kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;            \
+            rb[i_] = buffer_load16(xs_, ok_ ? ri_[i_].x + delta_ : OOB_OFFSET);                                     \
+            ra[i_] = buffer_load16(ys_, (nvalid && ri_[i_].y != OOB_OFFSET) ? ri_[i_].y + dyo : OOB_OFFSET);        \
+        }                                                                                                           \
+    }
+#define WG_STORE(BUF)                                                                                               \
+    {                                                                                                               \
+        char* A_ = lds + (BUF) * 2 * WG_TILE_B;                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+            *reinterpret_cast<uint4*>(A_ + st_off + i_ * 16 * WG_ROWB) = ra[i_];                                    \
+            *reinterpret_cast<uint4*>(A_ + WG_TILE_B + st_off + i_ * 16 * WG_ROWB) = rb[i_];                        \
+        }                                                                                                           \
+    }
+
+    WG_LOAD(tlo);
+    WG_STORE(0);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int tile = tlo; tile < thi; ++tile) {
+        const bool more = tile + 1 < thi;
+        if (more) WG_LOAD(tile + 1);
+        const char* A = lds + cur * 2 * WG_TILE_B;     // dY tile
+        const char* B = A + WG_TILE_B;                 // X tile
+        if constexpr (ES == 2) {
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            const int swz = (g & 1) << 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row = 32 * s + 8 * g + q;
+                s16x8 af[FI], bf[FI];
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const int ca = (wm * WT + 16 * i + 4 * pp) * 2;       // byte column inside the 256-byte row
+                    const int aoff = row * WG_ROWB + ((((ca >> 4) ^ swz)) << 4) + (ca & 15);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WG_ROWB));
+                    af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int cb = (wn * WT + 16 * i + 4 * pp) * 2;
+                    const int boff = row * WG_ROWB + ((((cb >> 4) ^ swz)) << 4) + (cb & 15);
+                    const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
+                    const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WG_ROWB));
+                    bf[i] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int li = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int row = 4 * s + kq;
+                const int swz = ((row >> 3) & 1) << 3;
+                float af[FI], bf[FI];
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const int ca = (wm * WT + 16 * i + li) * 4;
+                    af[i] = *reinterpret_cast<const float*>(A + row * WG_ROWB + (((ca >> 4) ^ swz) << 4) + (ca & 15));
+                    const int cb = (wn * WT + 16 * i + li) * 4;
+                    bf[i] = *reinterpret_cast<const float*>(B + row * WG_ROWB + (((cb >> 4) ^ swz) << 4) + (cb & 15));
+                }
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) WG_STORE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef WG_LOAD
+#undef WG_STORE
+
+    // D[row = n][col = k]: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
+    const int lr = (lane >> 4) * 4, lc = lane & 15;
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FI; ++j) {
+            const int kc = k0 + wn * WT + 16 * j + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * WT + 16 * i + lr + r;
+                if (n < p.N && kc < p.Ktot) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+template <int ES>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const char* __restrict__ dy, long long rows, int N, long long ld_b,
+                                                        float* __restrict__ db) {
+    // thread = one 16-byte chunk column, strided over rows; partial sums combined with one atomic per chunk element
+    constexpr int CE = 16 / ES;
+    const int nch = (N + CE - 1) / CE;
+    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) % nch;
+    const long long rstart = (blockIdx.x * (long long)blockDim.x + threadIdx.x) / nch;
+    const long long rstride = ((long long)gridDim.x * blockDim.x) / nch;
+    if (rstride == 0 || rstart >= rstride) return;      // leftover threads would double-count row class 0
+    float s[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) s[j] = 0.f;
+    for (long long r = rstart; r < rows; r += rstride) {
+        const uint4 q = *reinterpret_cast<const uint4*>(dy + r * ld_b + (long long)chunk * 16);
+        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+        if constexpr (ES == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[2 * j] += __uint_as_float(w4[j] << 16);
+                s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CE; ++j)
+        if (chunk * CE + j < N) unsafeAtomicAdd(db + chunk * CE + j, s[j]);
+}
+
+// out[b][2*oy][2*ox][:] = in[b][oy][ox][:], zeros elsewhere; out is [B][Hu][Wu][C]
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int B, int H, int W,
+                                                           int Hu, int Wu, int cv) {
+    const long long total = (long long)B * Hu * Wu * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int x = (int)(r % Wu);
+        r /= Wu;
+        const int y = (int)(r % Hu);
+        const int b = (int)(r / Hu);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!(x & 1) && !(y & 1) && (y >> 1) < H && (x >> 1) < W) v = in[(((long long)b * H + (y >> 1)) * W + (x >> 1)) * cv + c];
+        out[i] = v;
+    }
+}
+
+// d_src[b][sy][sx][:] (+)= sum over destination pixels (y,x) with floor(y*rh)==sy (clamped) && floor(x*rw)==sx of d_dst
+template <int ES>
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const char* __restrict__ d_dst, char* __restrict__ d_src, int B,
+                                                               int Hd, int Wd, int Hs, int Ws, int C, float rh, float rw, int accumulate) {
+    constexpr int CE = 16 / ES;
+    const int cv = C / CE;
+    const long long total = (long long)B * Hs * Ws * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int sx = (int)(r % Ws);
+        r /= Ws;
+        const int sy = (int)(r % Hs);
+        const int b = (int)(r / Hs);
+        float s[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) s[j] = 0.f;
+        // candidate destination rows: the preimage of sy under y -> min(floor(y*rh), Hs-1) is a short contiguous run
+        int y0 = (int)floorf((float)sy / rh) - 1; if (y0 < 0) y0 = 0;
+        int x0 = (int)floorf((float)sx / rw) - 1; if (x0 < 0) x0 = 0;
+        for (int y = y0; y < Hd; ++y) {
+            int my = (int)floorf((float)y * rh); my = my < Hs - 1 ? my : Hs - 1;
+            if (my < sy) continue;
+            if (my > sy) break;
+            for (int x = x0; x < Wd; ++x) {
+                int mx = (int)floorf((float)x * rw); mx = mx < Ws - 1 ? mx : Ws - 1;
+                if (mx < sx) continue;
+                if (mx > sx) break;
+                const uint4 q = *reinterpret_cast<const uint4*>(d_dst + ((((long long)b * Hd + y) * Wd + x) * C + c * CE) * ES);
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[2 * j] += __uint_as_float(w4[j] << 16); s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
+                }
+            }
+        }
+        char* op = d_src + i * 16;
+        if (accumulate) {
+            const uint4 q = *reinterpret_cast<const uint4*>(op);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[2 * j] += __uint_as_float(w4[j] << 16); s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
+            }
+        }
+        uint4 o;
+        if constexpr (ES == 2) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bf16x2 v = {(__bf16)s[2 * j], (__bf16)s[2 * j + 1]}; w[j] = __builtin_bit_cast(unsigned, v); }
+            o = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            o = make_uint4(__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3]));
+        }
+        *reinterpret_cast<uint4*>(op) = o;
+    }
+}
+
+// gradient goes to the first window position (row-major scan) holding the maximum — TF MaxPoolGrad's choice
+template <int ES>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const char* __restrict__ x, const char* __restrict__ dy, float* __restrict__ dx32,
+                                                          int B, int Hin, int Win, int C, int Hout, int Wout, int pad_t, int pad_l) {
+    constexpr int CE = 16 / ES;
+    const int cv = C / CE;
+    const long long total = (long long)B * Hout * Wout * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % Wout);
+        r /= Wout;
+        const int oy = (int)(r % Hout);
+        const int b = (int)(r / Hout);
+        float mx[CE];
+        int arg[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) { mx[j] = -INFINITY; arg[j] = -1; }
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - pad_t + kh;
+            if ((unsigned)iy >= (unsigned)Hin) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - pad_l + kw;
+                if ((unsigned)ix >= (unsigned)Win) continue;
+                const int pix = iy * Win + ix;
+                const uint4 q = *reinterpret_cast<const uint4*>(x + (((long long)b * Hin * Win + pix) * C + cc * CE) * ES);
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                float v[CE];
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w4[j] << 16); v[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(w4[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < CE; ++j)
+                    if (v[j] > mx[j]) { mx[j] = v[j]; arg[j] = pix; }
+            }
+        }
+        const uint4 gq = *reinterpret_cast<const uint4*>(dy + i * 16);
+        const unsigned g4[4] = {gq.x, gq.y, gq.z, gq.w};
+        float g[CE];
+        if constexpr (ES == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g[2 * j] = __uint_as_float(g4[j] << 16); g[2 * j + 1] = __uint_as_float(g4[j] & 0xffff0000u); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = __uint_as_float(g4[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CE; ++j)
+            if (arg[j] >= 0 && g[j] != 0.f)
+                unsafeAtomicAdd(dx32 + ((long long)b * Hin * Win + arg[j]) * C + cc * CE + j, g[j]);
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ in, char* __restrict__ out, long long n,
+                                                            const char* __restrict__ relu_src) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float val = in[i];
+        if (relu_src) {
+            float xv;
+            if constexpr (ES == 2) xv = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(relu_src)[i]) << 16);
+            else xv = reinterpret_cast<const float*>(relu_src)[i];
+            if (!(xv > 0.f)) val = 0.f;
+        }
+        if constexpr (ES == 2) {
+            const __bf16 hb = (__bf16)val;
+            reinterpret_cast<unsigned short*>(out)[i] = __builtin_bit_cast(unsigned short, hb);
+        } else {
+            reinterpret_cast<float*>(out)[i] = val;
+        }
+    }
+}
+
+// out[r][0..cout) = cast(in[r][0..cin)), zero for c >= cin   (f32 loss gradients -> 64-channel dY of the head outputs)
+template <int ES>
+__global__ __launch_bounds__(256) void pad_cast_rows_kernel(const float* __restrict__ in, char* __restrict__ out, long long rows,
+                                                            int cin, int cout) {
+    const long long total = rows * cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cout;
+        const int c = (int)(i - r * cout);
+        const float v = c < cin ? in[r * cin + c] : 0.f;
+        if constexpr (ES == 2) {
+            const __bf16 hb = (__bf16)v;
+            reinterpret_cast<unsigned short*>(out)[i] = __builtin_bit_cast(unsigned short, hb);
+        } else {
+            reinterpret_cast<float*>(out)[i] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over i of (g[i]*scale[i])^2 -> partial per block (fixed order), finished by sumsq_final
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const float* __restrict__ scale, long long n,
+                                                    double* __restrict__ partial) {
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = g[i] * (scale ? scale[i] : 1.f);
+        s += (double)v * (double)v;
+    }
+    __shared__ double sh[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) v += partial[i];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// Keras-2 Adam (RetinaNet.py:130: lr, beta 0.9/0.999, epsilon 1e-7, no decay) with global-norm clipping:
+//   g = grad * scale * min(1, clipnorm / norm);  lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr_t * m / (sqrt(v) + eps)
+// and re-emission of the forward weights  w_fwd = cast(w * fold)  (fold = frozen-BN scale per output channel, 1 elsewhere).
+template <int ES>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, const float* __restrict__ gscale,
+                                                   const float* __restrict__ fold, char* __restrict__ w_fwd, long long n, float lr_t,
+                                                   float b1, float b2, float eps, const double* __restrict__ sumsq, float clipnorm,
+                                                   float grad_mul) {
+    float clip = 1.f;
+    if (clipnorm > 0.f && sumsq) {
+        const float norm = sqrtf((float)sumsq[0]) * fabsf(grad_mul);
+        if (norm > clipnorm) clip = clipnorm / norm;
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * (gscale ? gscale[i] : 1.f) * grad_mul * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float wi = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; w[i] = wi;
+        if (w_fwd) {
+            const float wf = wi * (fold ? fold[i] : 1.f);
+            if constexpr (ES == 2) {
+                const __bf16 hb = (__bf16)wf;
+                reinterpret_cast<unsigned short*>(w_fwd)[i] = __builtin_bit_cast(unsigned short, hb);
+            } else {
+                reinterpret_cast<float*>(w_fwd)[i] = wf;
+            }
+        }
+    }
+}
+
+inline unsigned grid_for(long long work, int cap = 4096) {
+    long long g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
+    if (!d || d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS) return 0;
+    long long tiles = 0;
+    for (int i = 0; i < d->ngroups; ++i) tiles += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 63) / 64;
+    return (size_t)tiles * 64 * sizeof(uint4);
+}
+
+extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (!d || !dW || !workspace) return rtn_fail(h, RTN_EINVAL, "wgrad: null argument");
+    if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "wgrad: bad dtype");
+    const int es = rtn_dtype_size(d->dtype);
+    if (d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS || d->batch < 1 || d->N < 1) return rtn_fail(h, RTN_EINVAL, "wgrad: bad group/batch/N");
+    const int cshift = ilog2_exact(d->Crun);
+    if (cshift < 0 || (d->Crun * es) % 16) return rtn_fail(h, RTN_EINVAL, "wgrad: Crun %d", d->Crun);
+    const long long Ktot = (long long)d->KH * d->KW * d->Crun;
+    if ((Ktot * es) % 16 || Ktot > (1 << 24)) return rtn_fail(h, RTN_EINVAL, "wgrad: K %lld", Ktot);
+    if ((d->N * es) % 16 || (d->out_ld * es) % 16) return rtn_fail(h, RTN_EINVAL, "wgrad: N %d / out_ld %d must span whole 16-byte chunks (pad dY)", d->N, d->out_ld);
+    if (d->w_rows < d->N) return rtn_fail(h, RTN_EINVAL, "wgrad: w_rows < N");
+    if (((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return rtn_fail(h, RTN_EINVAL, "wgrad: dW/workspace alignment");
+    const long long pix_b = (long long)d->pix_stride * es;
+    if (pix_b % 16 && (d->KW != 1 || (d->sx * pix_b) % 16 || (d->pad_l * pix_b) % 16)) return rtn_fail(h, RTN_EINVAL, "wgrad: unaligned taps");
+    if (workspace_bytes < rtn_conv2d_wgrad_workspace_bytes(d)) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, rtn_conv2d_wgrad_workspace_bytes(d));
+
+    WParams p;
+    memset(&p, 0, sizeof(p));
+    long long tiles = 0;
+    for (int i = 0; i < d->ngroups; ++i) {
+        const rtn_conv_group_t& s = d->g[i];
+        WGroup& g = p.g[i];
+        if (!s.in || !s.out) return rtn_fail(h, RTN_EINVAL, "wgrad: group %d null x/dY", i);
+        if (((uintptr_t)s.in & 15) || ((uintptr_t)s.out & 15)) return rtn_fail(h, RTN_EINVAL, "wgrad: group %d alignment", i);
+        if (s.Hin < 1 || s.Win < 1 || s.Hout < 1 || s.Wout < 1 || s.Hout > 32000 || s.Wout > 32000) return rtn_fail(h, RTN_EINVAL, "wgrad: group %d extent", i);
+        if ((s.in_img_stride * es) % 16 || ((long long)s.in_row_stride * es) % 16 || (s.out_img_stride * es) % 16 || (s.out_off * es) % 16)
+            return rtn_fail(h, RTN_EINVAL, "wgrad: group %d strides not 16-byte multiples", i);
+        const long long in_max = (long long)(d->batch - 1) * s.in_img_stride + (long long)(s.Hin - 1) * s.in_row_stride + (long long)(s.Win - 1) * d->pix_stride + d->Crun;
+        if (in_max > s.in_elems) return rtn_fail(h, RTN_EBOUNDS, "wgrad: group %d x taps reach %lld of %lld", i, in_max, (long long)s.in_elems);
+        const long long cells = (long long)s.Hout * s.Wout;
+        const long long dy_max = (long long)(d->batch - 1) * s.out_img_stride + s.out_off + (cells - 1) * d->out_ld + d->N;
+        if (s.out_off < 0 || dy_max > s.out_elems) return rtn_fail(h, RTN_EBOUNDS, "wgrad: group %d dY reads reach %lld of %lld", i, dy_max, (long long)s.out_elems);
+        if (s.in_elems * es >= (long long)OOB_OFFSET || s.out_elems * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "wgrad: group %d tensor exceeds the 4 GiB descriptor range", i);
+        g.x = (const char*)s.in; g.dy = (const char*)s.out;
+        g.x_bytes = (unsigned)(s.in_elems * es); g.dy_bytes = (unsigned)(s.out_elems * es);
+        g.x_img_stride_b = s.in_img_stride * es;
+        g.dy_img_stride_b = s.out_img_stride * es;
+        g.dy_off_b = s.out_off * es;
+        g.x_row_stride_b = (int)((long long)s.in_row_stride * es);
+        g.Hin = s.Hin; g.Win = s.Win; g.Hout = s.Hout; g.Wout = s.Wout;
+        g.M = (int)(cells * d->batch);
+        g.tile_begin = (int)tiles;
+        tiles += (cells * d->batch + 63) / 64;
+    }
+    if (tiles > (1 << 24)) return rtn_fail(h, RTN_EINVAL, "wgrad: too many pixels");
+    const int CH = es == 2 ? 128 : 64;
+    p.dW = dW;
+    p.rowinfo = (const uint4*)workspace;
+    p.ngroups = d->ngroups;
+    p.total_tiles = (int)tiles;
+    p.N = d->N;
+    p.Ktot = (int)Ktot;
+    p.cshift = cshift; p.crun_mask = d->Crun - 1; p.KW = d->KW;
+    p.kw_inv = (65536 + d->KW - 1) / d->KW;
+    for (int kp = 0; kp < d->KH * d->KW; ++kp)
+        if (((kp * p.kw_inv) >> 16) != kp / d->KW) return rtn_fail(h, RTN_EINVAL, "wgrad: KW %d unsupported", d->KW);
+    p.pix_stride_b = (int)pix_b;
+    p.sy = d->sy; p.sx = d->sx; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.dy_ld_b = d->out_ld * es;
+    const int ntn = (d->N + CH - 1) / CH;
+    p.ntiles_k = (int)((Ktot + CH - 1) / CH);
+    const long long out_tiles = (long long)ntn * p.ntiles_k;
+    long long nsplit = (1024 + out_tiles - 1) / out_tiles;
+    if (nsplit > tiles) nsplit = tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    p.tiles_per_split = (int)((tiles + nsplit - 1) / nsplit);
+    nsplit = (tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+
+    if (es == 2) hipLaunchKernelGGL((wgrad_rowinfo_kernel<2>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
+    else         hipLaunchKernelGGL((wgrad_rowinfo_kernel<4>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
+    RTN_CHECK_LAUNCH(h, "wgrad_rowinfo_kernel");
+    dim3 grid((unsigned)out_tiles, (unsigned)nsplit);
+    if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
+    else         hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
+    RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_bias_grad(rtn_handle_t h, const void* dy, int dtype, int64_t rows, int N, int64_t ld, float* db) {
+    if (!h) return RTN_EINVAL;
+    if (!dy || !db || rows < 1 || N < 1 || ld < N) return rtn_fail(h, RTN_EINVAL, "bias_grad: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "bias_grad: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((ld * es) % 16 || ((uintptr_t)dy & 15)) return rtn_fail(h, RTN_EINVAL, "bias_grad: ld/pointer not 16-byte aligned");
+    const int ce = 16 / es, nch = (N + ce - 1) / ce;
+    if ((long long)nch * ce > ld) return rtn_fail(h, RTN_EINVAL, "bias_grad: last chunk leaves the row");
+    long long threads = (long long)nch * ((rows + 63) / 64);
+    if (threads < nch) threads = nch;
+    long long blocks = (threads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    // the kernel needs gridDim*256 to be a multiple of nch-aligned strides: rstride = total/nch (floor) is fine
+    if (es == 2) hipLaunchKernelGGL((bias_grad_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (const char*)dy, (long long)rows, N, (long long)ld * es, db);
+    else         hipLaunchKernelGGL((bias_grad_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (const char*)dy, (long long)rows, N, (long long)ld * es, db);
+    RTN_CHECK_LAUNCH(h, "bias_grad_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_zero_insert2(rtn_handle_t h, const void* in, void* out, int dtype, int B, int H, int W, int C, int Hu, int Wu) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || B < 1 || H < 1 || W < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "zero_insert2: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "zero_insert2: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return rtn_fail(h, RTN_EINVAL, "zero_insert2: alignment");
+    if (Hu < 2 * H - 1 || Wu < 2 * W - 1) return rtn_fail(h, RTN_EINVAL, "zero_insert2: %dx%d too small for %dx%d", Hu, Wu, H, W);
+    const int cv = C * es / 16;
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3(grid_for((long long)B * Hu * Wu * cv)), dim3(256), 0, h->stream, (const uint4*)in, (uint4*)out, B, H, W, Hu, Wu, cv);
+    RTN_CHECK_LAUNCH(h, "zero_insert2_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_upsample_add_bwd(rtn_handle_t h, const void* d_dst, void* d_src, int dtype, int B, int Hd, int Wd, int Hs, int Ws,
+                                    int C, int accumulate) {
+    if (!h) return RTN_EINVAL;
+    if (!d_dst || !d_src || B < 1 || Hd < 1 || Wd < 1 || Hs < 1 || Ws < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "upsample_add_bwd: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "upsample_add_bwd: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) return rtn_fail(h, RTN_EINVAL, "upsample_add_bwd: alignment");
+    const float rh = (float)Hs / (float)Hd, rw = (float)Ws / (float)Wd;
+    const long long total = (long long)B * Hs * Ws * (C * es / 16);
+    if (es == 2) hipLaunchKernelGGL((upsample_add_bwd_kernel<2>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)d_dst, (char*)d_src, B, Hd, Wd, Hs, Ws, C, rh, rw, accumulate);
+    else         hipLaunchKernelGGL((upsample_add_bwd_kernel<4>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)d_dst, (char*)d_src, B, Hd, Wd, Hs, Ws, C, rh, rw, accumulate);
+    RTN_CHECK_LAUNCH(h, "upsample_add_bwd_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_maxpool3x3s2_tfsame_bwd(rtn_handle_t h, const void* x, const void* dy, void* dx, int dtype, int B, int Hin, int Win,
+                                           int C, float* scratch_f32, int relu_mask) {
+    if (!h) return RTN_EINVAL;
+    if (!x || !dy || !dx || !scratch_f32 || B < 1 || Hin < 1 || Win < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd: alignment");
+    const int Hout = (Hin + 1) / 2, Wout = (Win + 1) / 2;
+    int pth = (Hout - 1) * 2 + 3 - Hin; if (pth < 0) pth = 0;
+    int ptw = (Wout - 1) * 2 + 3 - Win; if (ptw < 0) ptw = 0;
+    const long long nin = (long long)B * Hin * Win * C;
+    RTN_HIP(h, hipMemsetAsync(scratch_f32, 0, (size_t)nin * 4, h->stream));
+    const long long total = (long long)B * Hout * Wout * (C * es / 16);
+    if (es == 2) hipLaunchKernelGGL((maxpool_bwd_kernel<2>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)x, (const char*)dy, scratch_f32, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    else         hipLaunchKernelGGL((maxpool_bwd_kernel<4>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)x, (const char*)dy, scratch_f32, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    RTN_CHECK_LAUNCH(h, "maxpool_bwd_kernel");
+    if (es == 2) hipLaunchKernelGGL((cast_from_f32_kernel<2>), dim3(grid_for(nin)), dim3(256), 0, h->stream, (const float*)scratch_f32, (char*)dx, nin, relu_mask ? (const char*)x : (const char*)nullptr);
+    else         hipLaunchKernelGGL((cast_from_f32_kernel<4>), dim3(grid_for(nin)), dim3(256), 0, h->stream, (const float*)scratch_f32, (char*)dx, nin, relu_mask ? (const char*)x : (const char*)nullptr);
+    RTN_CHECK_LAUNCH(h, "cast_from_f32_kernel");
+    return RTN_OK;
+}
+
+extern "C" size_t rtn_sumsq_workspace_bytes(void) { return 2048 * sizeof(double); }
+
+extern "C" int rtn_sumsq(rtn_handle_t h, const float* g, const float* scale, int64_t n, double* out, void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (!g || !out || !workspace || n < 1) return rtn_fail(h, RTN_EINVAL, "sumsq: bad argument");
+    if (workspace_bytes < rtn_sumsq_workspace_bytes()) return rtn_fail(h, RTN_ENOMEM, "sumsq: workspace too small");
+    const unsigned nb = grid_for(n, 2048);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, h->stream, g, scale, (long long)n, (double*)workspace);
+    RTN_CHECK_LAUNCH(h, "sumsq_kernel");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)workspace, (int)nb, out);
+    RTN_CHECK_LAUNCH(h, "sumsq_final_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_adam_clipnorm_step(rtn_handle_t h, float* w, float* m, float* v, const float* g, const float* gscale,
+                                      const float* fold, void* w_fwd, int fwd_dtype, int64_t n, int64_t step, float lr, float beta1,
+                                      float beta2, float eps, const double* sumsq, float clipnorm, float grad_mul) {
+    if (!h) return RTN_EINVAL;
+    if (!w || !m || !v || !g || n < 1 || step < 1) return rtn_fail(h, RTN_EINVAL, "adam: bad argument");
+    if (w_fwd && fwd_dtype != RTN_BF16 && fwd_dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "adam: bad forward dtype");
+    // Keras 2: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    const unsigned nb = grid_for(n, 4096);
+    if (fwd_dtype == RTN_BF16)
+        hipLaunchKernelGGL((adam_kernel<2>), dim3(nb), dim3(256), 0, h->stream, w, m, v, g, gscale, fold, (char*)w_fwd, (long long)n, (float)lr_t, beta1, beta2, eps, sumsq, clipnorm, grad_mul);
+    else
+        hipLaunchKernelGGL((adam_kernel<4>), dim3(nb), dim3(256), 0, h->stream, w, m, v, g, gscale, fold, (char*)w_fwd, (long long)n, (float)lr_t, beta1, beta2, eps, sumsq, clipnorm, grad_mul);
+    RTN_CHECK_LAUNCH(h, "adam_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_pad_cast_rows(rtn_handle_t h, const float* in, void* out, int dtype, int64_t rows, int cin, int cout) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || rows < 1 || cin < 1 || cout < cin) return rtn_fail(h, RTN_EINVAL, "pad_cast_rows: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "pad_cast_rows: bad dtype");
+    const unsigned nb = grid_for((long long)rows * cout);
+    if (dtype == RTN_BF16) hipLaunchKernelGGL((pad_cast_rows_kernel<2>), dim3(nb), dim3(256), 0, h->stream, in, (char*)out, (long long)rows, cin, cout);
+    else                   hipLaunchKernelGGL((pad_cast_rows_kernel<4>), dim3(nb), dim3(256), 0, h->stream, in, (char*)out, (long long)rows, cin, cout);
+    RTN_CHECK_LAUNCH(h, "pad_cast_rows_kernel");
+    return RTN_OK;
+}

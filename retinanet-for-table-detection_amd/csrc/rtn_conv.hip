@@ -66,6 +66,9 @@ struct KGroup {
     const char* in;
     char* out;
     const char* res;
+    const char* mask;
+    long long mask_img_stride;  // elements
+    int mask_ld, out_step, out_pix_w;
     unsigned in_bytes;          // size of `in` (buffer descriptor range)
     long long in_img_stride_b;  // bytes
     long long out_img_stride;   // elements
@@ -117,20 +120,28 @@ __device__ __forceinline__ void mma_step(f32x4& acc, const uint4& a, const uint4
 // row costs one HBM round trip per row: 25 % of the HBM-bound 1x1 layers' time when it was written that way).
 template <int ES>
 struct ResVec {
-    uint4 q[ES == 2 ? 1 : 2];
+    uint4 q[ES == 2 ? 1 : 2];     // residual
+    uint4 k[ES == 2 ? 1 : 2];     // ReLU mask source
 };
 
 struct RowRef {
-    int b, cell;
+    int b, cell;       // image, dense output pixel index (oy*Wout + ox)
+    long long opix;    // pixel index inside the `out` / `res` / `mask` images (differs from cell when out_step > 1)
     bool valid;
 };
 
-__device__ __forceinline__ RowRef row_ref(int m, int M, int cells) {
+__device__ __forceinline__ RowRef row_ref(const KGroup& G, int m, int M, int cells, int Wout) {
     RowRef r;
     r.valid = m < M;
     const int mc = r.valid ? m : M - 1;            // clamped: address math and loads stay unconditional
     r.b = mc / cells;
     r.cell = mc - r.b * cells;
+    if (G.out_step > 1) {
+        const int oy = r.cell / Wout, ox = r.cell - oy * Wout;
+        r.opix = (long long)oy * G.out_step * G.out_pix_w + (long long)ox * G.out_step;
+    } else {
+        r.opix = r.cell;
+    }
     return r;
 }
 
@@ -147,7 +158,7 @@ __device__ __forceinline__ const char* res_ptr(const KParams& p, const KGroup& G
         sx_ = sx_ < G.Wres - 1 ? sx_ : G.Wres - 1;
         rpix = (long long)sy_ * G.Wres + sx_;
     } else {
-        rpix = r.cell;
+        rpix = r.opix;
     }
     return G.res + ((long long)r.b * G.res_img_stride + rpix * G.res_ld + n) * ES;
 }
@@ -157,6 +168,13 @@ __device__ __forceinline__ void res_prefetch(const KParams& p, const KGroup& G, 
     const char* rp = res_ptr<ES>(p, G, r, Wout, n);
     out.q[0] = *reinterpret_cast<const uint4*>(rp);
     if constexpr (ES == 4) out.q[1] = *reinterpret_cast<const uint4*>(rp + 16);
+}
+
+template <int ES>
+__device__ __forceinline__ void mask_prefetch(const KGroup& G, const RowRef& r, int n, ResVec<ES>& out) {
+    const char* mp = G.mask + ((long long)r.b * G.mask_img_stride + r.opix * G.mask_ld + n) * ES;
+    out.k[0] = *reinterpret_cast<const uint4*>(mp);
+    if constexpr (ES == 4) out.k[1] = *reinterpret_cast<const uint4*>(mp + 16);
 }
 
 __device__ __forceinline__ void load_bias8(const KParams& p, int n, float (&bv)[8]) {
@@ -170,6 +188,25 @@ __device__ __forceinline__ void load_bias8(const KParams& p, int n, float (&bv)[
     }
 }
 
+// zero v[j] where the prefetched mask element is not > 0
+template <int ES>
+__device__ __forceinline__ void apply_relu_mask(const ResVec<ES>& pre, float (&v)[8]) {
+    if constexpr (ES == 2) {
+        const unsigned w4[4] = {pre.k[0].x, pre.k[0].y, pre.k[0].z, pre.k[0].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!(__uint_as_float(w4[j] << 16) > 0.f)) v[2 * j] = 0.f;
+            if (!(__uint_as_float(w4[j] & 0xffff0000u) > 0.f)) v[2 * j + 1] = 0.f;
+        }
+    } else {
+        const unsigned w8[8] = {pre.k[0].x, pre.k[0].y, pre.k[0].z, pre.k[0].w, pre.k[ES == 4 ? 1 : 0].x,
+                                pre.k[ES == 4 ? 1 : 0].y, pre.k[ES == 4 ? 1 : 0].z, pre.k[ES == 4 ? 1 : 0].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!(__uint_as_float(w8[j]) > 0.f)) v[j] = 0.f;
+    }
+}
+
 // bias -> residual -> ReLU / sigmoid -> bf16 or f32 store at the group's offsets.  `pre` is the prefetched residual
 // (used when res_vec), otherwise an unaligned / partial residual is read element-wise here.
 template <int ES>
@@ -180,6 +217,7 @@ __device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup&
     const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += bv[j];
+    if ((flags & RTN_CONV_RELU_MASK) && (flags & RTN_CONV_MASK_PRE)) apply_relu_mask<ES>(pre, v);
     if (flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) {
         if (res_vec) {
             if constexpr (ES == 2) {
@@ -205,6 +243,7 @@ __device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup&
             }
         }
     }
+    if ((flags & RTN_CONV_RELU_MASK) && !(flags & RTN_CONV_MASK_PRE)) apply_relu_mask<ES>(pre, v);   // vec_ok guaranteed by the host
     if (flags & RTN_CONV_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
@@ -213,7 +252,7 @@ __device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup&
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
     }
-    const long long oidx = (long long)r.b * G.out_img_stride + G.out_off + (long long)r.cell * p.out_ld + n;
+    const long long oidx = (long long)r.b * G.out_img_stride + G.out_off + r.opix * p.out_ld + n;
     const bool out_f32 = (ES == 4) || (flags & RTN_CONV_OUT_F32);
     if (out_f32) {
         float* op = reinterpret_cast<float*>(G.out) + oidx;
@@ -412,8 +451,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
     ResVec<ES> pre[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        rows[it] = row_ref(m0 + t / TPR + it * RPP, M, cells);
+        rows[it] = row_ref(G, m0 + t / TPR + it * RPP, M, cells, Wout);
         if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, n, pre[it]);
+        if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, rows[it], n, pre[it]);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -612,9 +652,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
         ResVec<ES> pre[NITW];
 #pragma unroll
         for (int it = 0; it < NITW; ++it) {
-            rows[it] = row_ref(m0 + wm * 64 + hh * 32 + lane / TPRW + it * RPPW, M, cells);
+            rows[it] = row_ref(G, m0 + wm * 64 + hh * 32 + lane / TPRW + it * RPPW, M, cells, Wout);
             rows[it].valid = rows[it].valid && ncol_ok;
             if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, ncol_ok ? n : 0, pre[it]);
+            if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, rows[it], ncol_ok ? n : 0, pre[it]);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -656,7 +697,7 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
+static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
@@ -718,17 +759,31 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         const long long cells = (long long)s.Hout * s.Wout;
         const long long M = cells * d->batch;
         if (M > (1ll << 30)) return rtn_fail(h, RTN_EINVAL, "conv: M too large");
-        const long long out_max = (long long)(d->batch - 1) * s.out_img_stride + s.out_off + (cells - 1) * d->out_ld + d->N;
+        const int ostep = s.out_step > 1 ? s.out_step : 1;
+        if (ostep > 1 && s.out_pix_w < (s.Wout - 1) * ostep + 1) return rtn_fail(h, RTN_EINVAL, "conv: group %d out_pix_w %d too small for out_step %d", i, s.out_pix_w, ostep);
+        const long long last_pix = ostep > 1 ? (long long)(s.Hout - 1) * ostep * s.out_pix_w + (long long)(s.Wout - 1) * ostep : cells - 1;
+        const long long out_max = (long long)(d->batch - 1) * s.out_img_stride + s.out_off + last_pix * d->out_ld + d->N;
         if (s.out_off < 0 || out_max > s.out_elems) return rtn_fail(h, RTN_EBOUNDS, "conv: group %d writes reach element %lld of a %lld-element output", i, out_max, (long long)s.out_elems);
         if (s.out_img_stride % 8 || s.out_off % 8) vec_ok = false;
         if (has_res) {
             if (!s.res) return rtn_fail(h, RTN_EINVAL, "conv: group %d residual flag without res", i);
-            const long long rcells = (d->flags & RTN_CONV_RES_UPSAMPLE) ? (long long)s.Hres * s.Wres : cells;
+            const long long rcells = (d->flags & RTN_CONV_RES_UPSAMPLE) ? (long long)s.Hres * s.Wres : last_pix + 1;
             if ((d->flags & RTN_CONV_RES_UPSAMPLE) && (s.Hres < 1 || s.Wres < 1)) return rtn_fail(h, RTN_EINVAL, "conv: group %d bad residual extent", i);
             const long long res_max = (long long)(d->batch - 1) * s.res_img_stride + (rcells - 1) * s.res_ld + d->N;
             if (res_max > s.res_elems) return rtn_fail(h, RTN_EBOUNDS, "conv: group %d residual reads reach %lld of %lld", i, res_max, (long long)s.res_elems);
             if (s.res_ld % 8 || s.res_img_stride % 8) vec_ok = false;
         }
+        if (d->flags & RTN_CONV_RELU_MASK) {
+            if (!s.mask || ((uintptr_t)s.mask & 15)) return rtn_fail(h, RTN_EINVAL, "conv: group %d RELU_MASK without an aligned mask", i);
+            const long long mask_max = (long long)(d->batch - 1) * s.mask_img_stride + last_pix * s.mask_ld + d->N;
+            if (mask_max > s.mask_elems) return rtn_fail(h, RTN_EBOUNDS, "conv: group %d mask reads reach %lld of %lld", i, mask_max, (long long)s.mask_elems);
+            if (s.mask_ld % 8 || s.mask_img_stride % 8) vec_ok = false;
+        }
+        g.mask = (const char*)s.mask;
+        g.mask_img_stride = s.mask_img_stride;
+        g.mask_ld = s.mask_ld;
+        g.out_step = ostep;
+        g.out_pix_w = s.out_pix_w;
         g.in = (const char*)s.in;
         g.out = (char*)s.out;
         g.res = (const char*)s.res;
@@ -748,6 +803,7 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         mtiles += (M + TM - 1) / TM;
     }
     (void)out_f32;
+    if ((d->flags & RTN_CONV_RELU_MASK) && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv: RELU_MASK needs N, out_ld, strides multiples of 8");
     const int BN = impl == 2 ? (d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256)) : (d->N <= 64 ? 64 : 128);
     p.w = (const char*)d->w;
     p.bias = d->bias;
@@ -797,5 +853,54 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) {
         }
     }
     RTN_CHECK_LAUNCH(h, "conv_igemm_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) { return conv_launch(h, d); }
+
+extern "C" int rtn_conv2d_dgrad(rtn_handle_t h, const rtn_conv_desc_t* d) {
+    if (!h) return RTN_EINVAL;
+    if (!d) return rtn_fail(h, RTN_EINVAL, "dgrad: null descriptor");
+    if (d->sy != 1 || d->sx != 1) return rtn_fail(h, RTN_EINVAL, "dgrad: runs as a stride-1 convolution over dY (use out_step / rtn_zero_insert2)");
+    if (d->flags & (RTN_CONV_RELU | RTN_CONV_SIGMOID | RTN_CONV_RES_UPSAMPLE)) return rtn_fail(h, RTN_EINVAL, "dgrad: forward-only epilogue flag set");
+    return conv_launch(h, d);
+}
+
+namespace {
+// w_d[c][(KH-1-kh, KW-1-kw, n)] = w[n][(kh, kw, c)];  rows c >= Cin and columns n >= N are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ wf, T* __restrict__ wd, int N, int KH, int KW,
+                                                         int Cin, int Crun, int rows_d) {
+    const long long Kd = (long long)KH * KW * Crun;
+    const long long total = (long long)rows_d * Kd;
+    const long long Kf = (long long)KH * KW * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / Kd);
+        const int r = (int)(i - (long long)c * Kd);
+        const int tap = r / Crun, n = r - tap * Crun;
+        const int khd = tap / KW, kwd = tap - khd * KW;
+        T v = T(0);
+        if (c < Cin && n < N) v = wf[(long long)n * Kf + ((long long)(KH - 1 - khd) * KW + (KW - 1 - kwd)) * Cin + c];
+        wd[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int rtn_pack_dgrad_weights(rtn_handle_t h, const void* w_fwd, void* w_dgrad, int dtype, int N, int w_rows_fwd, int KH,
+                                      int KW, int Cin, int Cout_run, int w_rows_dgrad) {
+    if (!h) return RTN_EINVAL;
+    if (!w_fwd || !w_dgrad || N < 1 || KH < 1 || KW < 1 || Cin < 1) return rtn_fail(h, RTN_EINVAL, "pack_dgrad: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "pack_dgrad: bad dtype");
+    if (w_rows_fwd < N || Cout_run < N || w_rows_dgrad < Cin) return rtn_fail(h, RTN_EINVAL, "pack_dgrad: rows %d/%d/%d too small for N %d Cin %d", w_rows_fwd, Cout_run, w_rows_dgrad, N, Cin);
+    const long long total = (long long)w_rows_dgrad * KH * KW * Cout_run;
+    long long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (dtype == RTN_BF16)
+        hipLaunchKernelGGL((pack_dgrad_kernel<unsigned short>), dim3((unsigned)g), dim3(256), 0, h->stream, (const unsigned short*)w_fwd,
+                           (unsigned short*)w_dgrad, N, KH, KW, Cin, Cout_run, w_rows_dgrad);
+    else
+        hipLaunchKernelGGL((pack_dgrad_kernel<float>), dim3((unsigned)g), dim3(256), 0, h->stream, (const float*)w_fwd, (float*)w_dgrad,
+                           N, KH, KW, Cin, Cout_run, w_rows_dgrad);
+    RTN_CHECK_LAUNCH(h, "pack_dgrad_kernel");
     return RTN_OK;
 }

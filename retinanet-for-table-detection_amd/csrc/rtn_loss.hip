@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(long long rows, int K, co
                                                        const float* __restrict__ regt, const float* __restrict__ cls,
                                                        const float* __restrict__ reg, float alpha, float gamma, float sigma2,
                                                        float inv_cls, float inv_reg, int wrt_logits, float* __restrict__ d_cls,
-                                                       float* __restrict__ d_reg) {
+                                                       float* __restrict__ d_reg, const double* __restrict__ sums) {
+    if (sums) {     // normalisers from the (all-reduced) forward sums: K.maximum(1, count), model/losses.py:42,88
+        inv_cls = 1.0f / fmaxf(1.0f, (float)sums[2]);
+        inv_reg = 1.0f / fmaxf(1.0f, (float)sums[3]);
+    }
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
         const float* l = lab + r * (K + 1);
         const float state = l[K];
@@ -186,7 +190,24 @@ extern "C" int rtn_retina_loss_bwd(rtn_handle_t h, int64_t rows, int num_classes
     const int nb = loss_blocks(rows);
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(nb), dim3(256), 0, h->stream, (long long)rows, num_classes, labels_batch,
                        regression_batch, classification, regression, alpha, gamma, sigma * sigma, inv_norm_cls, inv_norm_reg,
-                       wrt_logits, d_cls, d_reg);
+                       wrt_logits, d_cls, d_reg, (const double*)nullptr);
+    RTN_CHECK_LAUNCH(h, "loss_bwd_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_retina_loss_bwd_dev(rtn_handle_t h, int64_t rows, int num_classes, const float* labels_batch,
+                                       const float* regression_batch, const float* classification, const float* regression,
+                                       float alpha, float gamma, float sigma, const double* sums, int wrt_logits, float* d_cls,
+                                       float* d_reg) {
+    if (!h) return RTN_EINVAL;
+    if (rows < 1 || num_classes < 1) return rtn_fail(h, RTN_EINVAL, "loss_bwd_dev: rows %lld classes %d", (long long)rows, num_classes);
+    if (!labels_batch || !regression_batch || !classification || !regression || !d_cls || !d_reg || !sums)
+        return rtn_fail(h, RTN_EINVAL, "loss_bwd_dev: null pointer");
+    if (((uintptr_t)regression & 15) || ((uintptr_t)d_reg & 15)) return rtn_fail(h, RTN_EINVAL, "loss_bwd_dev: regression buffers not 16-byte aligned");
+    const int nb = loss_blocks(rows);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nb), dim3(256), 0, h->stream, (long long)rows, num_classes, labels_batch,
+                       regression_batch, classification, regression, alpha, gamma, sigma * sigma, 0.f, 0.f, wrt_logits, d_cls,
+                       d_reg, sums);
     RTN_CHECK_LAUNCH(h, "loss_bwd_kernel");
     return RTN_OK;
 }

@@ -1,0 +1,301 @@
+"""GPU parity of the backward primitives against torch-CPU float64 autograd (parity unpinned: TF's autodiff cannot run
+here; the mathematical gradient of the restated forward graph is the oracle).
+Tolerances: fp32 path 1e-4 of the gradient scale (exact-f32 MFMA chains + f32 atomics over thousands of pixels);
+bf16 path: inputs rounded to bf16 on both sides, 2e-2 of the scale (bf16 output rounding / f32 accumulation)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DT = {"f32": (torch.float32, 1), "bf16": (torch.bfloat16, 0)}
+
+
+def q(x, dtype):
+    return x.to(DT[dtype][0]).to(torch.float64)
+
+
+def tol(dtype):
+    return 1e-4 if dtype == "f32" else 2e-2
+
+
+def fwd_ref(x_nhwc, w_hwio, stride, pad_t, pad_l, Ho, Wo):
+    kh, kw = w_hwio.shape[0], w_hwio.shape[1]
+    H, W = x_nhwc.shape[1], x_nhwc.shape[2]
+    pb = max((Ho - 1) * stride + kh - pad_t - H, 0)
+    pr = max((Wo - 1) * stride + kw - pad_l - W, 0)
+    xp = F.pad(x_nhwc.permute(0, 3, 1, 2), (pad_l, pr, pad_t, pb))
+    return F.conv2d(xp, w_hwio.permute(3, 2, 0, 1), None, stride=stride)[:, :, :Ho, :Wo].permute(0, 2, 3, 1)
+
+
+def pack_fwd(w_hwio, dtype):
+    kh, kw, cin, cout = w_hwio.shape
+    rows = -(-cout // 128) * 128
+    wk = torch.zeros(rows, kh * kw * cin, dtype=torch.float64)
+    wk[:cout] = w_hwio.permute(3, 0, 1, 2).reshape(cout, -1)
+    return wk.to(DT[dtype][0]).to(DEV).contiguous(), rows
+
+
+CASES = [  # (H, W, cin, cout, k, stride, pad)  pad: int or "same"
+    (12, 17, 64, 64, 3, 1, 1),
+    (9, 13, 256, 64, 1, 1, 0),
+    (10, 11, 128, 256, 3, 1, "same"),
+    (17, 23, 256, 128, 1, 2, 0),          # stride-2 1x1 'valid': dgrad scatters with out_step 2
+    (25, 42, 512, 256, 3, 2, "same"),     # P6: dgrad on the zero-inserted dY
+    (13, 21, 256, 256, 3, 2, "same"),     # P7
+]
+
+
+def geometry(H, W, k, stride, pad):
+    if pad == "same":
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        pt = max((Ho - 1) * stride + k - H, 0) // 2
+        pl = max((Wo - 1) * stride + k - W, 0) // 2
+    else:
+        pt = pl = pad
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return Ho, Wo, pt, pl
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_dgrad_and_wgrad(pkg, handle, dtype, case):
+    L = pkg._lib
+    H, W, cin, cout, k, stride, pad = CASES[case]
+    B = 2
+    tdt, code = DT[dtype]
+    g = torch.Generator().manual_seed(100 + case)
+    x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype).requires_grad_(True)
+    w = q(torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin), dtype).requires_grad_(True)
+    Ho, Wo, pt, pl = geometry(H, W, k, stride, pad)
+    y = fwd_ref(x, w, stride, pt, pl, Ho, Wo)
+    dy = q(torch.randn(B, Ho, Wo, cout, generator=g, dtype=torch.float64), dtype)
+    other = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)       # gradient already accumulated
+    act = torch.randn(B, H, W, cin, generator=g, dtype=torch.float64)                  # forward activation (ReLU mask source)
+    dx_ref, dw_ref = torch.autograd.grad(y, [x, w], dy)
+    dx_ref = (dx_ref + other) * (q(act, dtype) > 0)
+
+    xd = x.detach().to(tdt).to(DEV).contiguous()
+    dyd = dy.to(tdt).to(DEV).contiguous()
+    wk, rows = pack_fwd(w.detach(), dtype)
+    # ---------------- dgrad
+    rows_d = -(-cin // 128) * 128
+    wd = torch.empty(rows_d, k * k * cout, dtype=tdt, device=DEV)
+    handle.check(L.lib.rtn_pack_dgrad_weights(handle.raw, wk.data_ptr(), wd.data_ptr(), code, cout, rows, k, k, cin, cout, rows_d))
+    dxd = other.to(tdt).to(DEV).contiguous()          # in/out: accumulate
+    actd = act.to(tdt).to(DEV).contiguous()
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, B, code
+    d.w, d.w_rows, d.N, d.KH, d.KW = wd.data_ptr(), rows_d, cin, k, k
+    d.Crun = d.pix_stride = cout
+    d.sy = d.sx = 1
+    d.out_ld = cin
+    d.flags = L.CONV_RES_SAME | L.CONV_RELU_MASK
+    grp = L.ConvGroup()
+    keep = []
+    if stride == 1:
+        src, Hs, Ws = dyd, Ho, Wo
+        d.pad_t, d.pad_l = k - 1 - pt, k - 1 - pl
+        grp.Hout, grp.Wout = H, W
+    elif k == 1:
+        src, Hs, Ws = dyd, Ho, Wo
+        d.pad_t = d.pad_l = 0
+        grp.Hout, grp.Wout = Ho, Wo
+        grp.out_step, grp.out_pix_w = 2, W
+        # the scattered gradient only exists on even pixels: the reference "other" contribution elsewhere stays as is,
+        # so compare on the sampled pixels and check the rest is untouched
+    else:
+        Hu, Wu = 2 * Ho - 1, 2 * Wo - 1
+        up = torch.empty(B, Hu, Wu, cout, dtype=tdt, device=DEV)
+        handle.check(L.lib.rtn_zero_insert2(handle.raw, dyd.data_ptr(), up.data_ptr(), code, B, Ho, Wo, cout, Hu, Wu))
+        keep.append(up)
+        src, Hs, Ws = up, Hu, Wu
+        d.pad_t, d.pad_l = k - 1 - pt, k - 1 - pl
+        grp.Hout, grp.Wout = H, W
+    grp.in_, grp.in_elems = src.data_ptr(), src.numel()
+    grp.in_img_stride, grp.in_row_stride = Hs * Ws * cout, Ws * cout
+    grp.Hin, grp.Win = Hs, Ws
+    grp.out, grp.out_elems, grp.out_img_stride = dxd.data_ptr(), dxd.numel(), H * W * cin
+    grp.res, grp.res_elems, grp.res_img_stride, grp.res_ld = dxd.data_ptr(), dxd.numel(), H * W * cin, cin
+    grp.mask, grp.mask_elems, grp.mask_img_stride, grp.mask_ld = actd.data_ptr(), actd.numel(), H * W * cin, cin
+    d.g[0] = grp
+    handle.check(L.lib.rtn_conv2d_dgrad(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    got = dxd.cpu().double()
+    scale = max(1.0, float(dx_ref.abs().max()))
+    if stride == 2 and k == 1:
+        err = float((got[:, ::2, ::2] - dx_ref[:, ::2, ::2]).abs().max())
+        rest = torch.ones(H, W, dtype=torch.bool)
+        rest[::2, ::2] = False
+        assert torch.equal(got[:, rest], q(other, dtype)[:, rest])        # untouched off the stride grid
+    else:
+        err = float((got - dx_ref).abs().max())
+    assert err <= tol(dtype) * scale, "dgrad err %.3e scale %.2f" % (err, scale)
+
+    # ---------------- wgrad (accumulates into a pre-filled buffer) and bias grad
+    d2 = L.ConvDesc()
+    d2.ngroups, d2.batch, d2.dtype = 1, B, code
+    d2.w_rows, d2.N, d2.KH, d2.KW = rows, cout, k, k
+    d2.Crun = d2.pix_stride = cin
+    d2.sy = d2.sx = stride
+    d2.pad_t, d2.pad_l = pt, pl
+    d2.out_ld = cout
+    g2 = L.ConvGroup()
+    g2.in_, g2.in_elems = xd.data_ptr(), xd.numel()
+    g2.in_img_stride, g2.in_row_stride = H * W * cin, W * cin
+    g2.Hin, g2.Win, g2.Hout, g2.Wout = H, W, Ho, Wo
+    g2.out, g2.out_elems, g2.out_img_stride = dyd.data_ptr(), dyd.numel(), Ho * Wo * cout
+    d2.g[0] = g2
+    wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d2))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dW = torch.full((rows, k * k * cin), 0.5, dtype=torch.float32, device=DEV)
+    handle.check(L.lib.rtn_conv2d_wgrad(handle.raw, C.byref(d2), dW.data_ptr(), ws.data_ptr(), wsb))
+    db = torch.full((rows,), 0.25, dtype=torch.float32, device=DEV)
+    handle.check(L.lib.rtn_bias_grad(handle.raw, dyd.data_ptr(), code, B * Ho * Wo, cout, cout, db.data_ptr()))
+    torch.cuda.synchronize()
+    want = dw_ref.permute(3, 0, 1, 2).reshape(cout, -1)
+    gotw = dW.cpu().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((gotw[:cout] - 0.5 - want).abs().max())
+    assert err <= tol(dtype) * scale, "wgrad err %.3e scale %.2f" % (err, scale)
+    assert torch.all(gotw[cout:] == 0.5)
+    wantb = dy.sum(dim=(0, 1, 2))
+    errb = float((db.cpu().double()[:cout] - 0.25 - wantb).abs().max())
+    assert errb <= tol(dtype) * max(1.0, float(wantb.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_wgrad_grouped_levels_and_padded_head_output(pkg, handle, dtype):
+    """Shared head weights: one wgrad launch over five pyramid levels; dY of the 36-channel output padded to 64."""
+    L = pkg._lib
+    tdt, code = DT[dtype]
+    B, cin, cout, cp = 2, 256, 36, 64
+    levels = [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)]
+    g = torch.Generator().manual_seed(7)
+    w = q(torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) / 48, dtype).requires_grad_(True)
+    total_cells = sum(h * wd for h, wd in levels)
+    dy32 = torch.randn(B, total_cells, cout, generator=g)                       # f32 loss gradient, concatenated levels
+    dyp = torch.empty(B, total_cells, cp, dtype=tdt, device=DEV)
+    dy32d = dy32.to(DEV)
+    handle.check(L.lib.rtn_pad_cast_rows(handle.raw, dy32d.data_ptr(), dyp.data_ptr(), code, B * total_cells, cout, cp))
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w_rows, d.N, d.KH, d.KW = 128, cp, 3, 3
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = 1
+    d.out_ld = cp
+    keep, want, off = [], 0, 0
+    for gi, (H, W) in enumerate(levels):
+        x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+        y = fwd_ref(x, w, 1, 1, 1, H, W)
+        dyl = q(dy32[:, off:off + H * W].double(), dtype).reshape(B, H, W, cout)
+        want = want + torch.autograd.grad(y, w, dyl)[0]
+        xd = x.to(tdt).to(DEV).contiguous()
+        keep.append(xd)
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems = dyp.data_ptr(), dyp.numel()
+        grp.out_img_stride, grp.out_off = total_cells * cp, off * cp
+        d.g[gi] = grp
+        off += H * W
+    wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dW = torch.zeros(128, 9 * cin, dtype=torch.float32, device=DEV)
+    handle.check(L.lib.rtn_conv2d_wgrad(handle.raw, C.byref(d), dW.data_ptr(), ws.data_ptr(), wsb))
+    torch.cuda.synchronize()
+    wantm = want.permute(3, 0, 1, 2).reshape(cout, -1)
+    got = dW.cpu().double()
+    assert float((got[:cout] - wantm).abs().max()) <= tol(dtype) * max(1.0, float(wantm.abs().max()))
+    assert torch.all(got[cout:] == 0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [((25, 42), (50, 84)), ((50, 84), (100, 167)), ((33, 25), (65, 50))])
+def test_upsample_add_bwd(pkg, handle, dtype, shape):
+    L = pkg._lib
+    tdt, code = DT[dtype]
+    (Hs, Ws), (Hd, Wd) = shape
+    B, Cc = 2, 64
+    g = torch.Generator().manual_seed(3)
+    dd = q(torch.randn(B, Hd, Wd, Cc, generator=g, dtype=torch.float64), dtype)
+    prev = q(torch.randn(B, Hs, Ws, Cc, generator=g, dtype=torch.float64), dtype)
+    ys = np.minimum(np.floor(np.arange(Hd, dtype=np.float32) * (np.float32(Hs) / np.float32(Hd))).astype(np.int64), Hs - 1)
+    xs = np.minimum(np.floor(np.arange(Wd, dtype=np.float32) * (np.float32(Ws) / np.float32(Wd))).astype(np.int64), Ws - 1)
+    want = torch.zeros(B, Hs, Ws, Cc, dtype=torch.float64)
+    want.index_put_((torch.arange(B)[:, None, None], torch.as_tensor(ys)[None, :, None], torch.as_tensor(xs)[None, None, :]), dd, accumulate=True)
+    for acc in (0, 1):
+        out = prev.to(tdt).to(DEV).contiguous()
+        ddd = dd.to(tdt).to(DEV).contiguous()
+        handle.check(L.lib.rtn_upsample_add_bwd(handle.raw, ddd.data_ptr(), out.data_ptr(), code, B, Hd, Wd, Hs, Ws, Cc, acc))
+        torch.cuda.synchronize()
+        w = want + (prev if acc else 0)
+        assert float((out.cpu().double() - w).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(w.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_maxpool_bwd(pkg, handle, dtype):
+    L = pkg._lib
+    tdt, code = DT[dtype]
+    B, H, W, Cc = 2, 21, 34, 64
+    g = torch.Generator().manual_seed(4)
+    x = torch.relu(q(torch.randn(B, H, W, Cc, generator=g, dtype=torch.float64), dtype))      # ReLU output: many exact zeros/ties
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = q(torch.randn(B, Ho, Wo, Cc, generator=g, dtype=torch.float64), dtype)
+    pth, ptw = max((Ho - 1) * 2 + 3 - H, 0), max((Wo - 1) * 2 + 3 - W, 0)
+    xr = x.clone().requires_grad_(True)
+    xp = F.pad(xr.permute(0, 3, 1, 2), (ptw // 2, ptw - ptw // 2, pth // 2, pth - pth // 2), value=float("-inf"))
+    y = F.max_pool2d(xp, 3, 2).permute(0, 2, 3, 1)
+    want = torch.autograd.grad(y, xr, dy)[0] * (x > 0)
+    xd, dyd = x.to(tdt).to(DEV).contiguous(), dy.to(tdt).to(DEV).contiguous()
+    dx = torch.empty_like(xd)
+    scratch = torch.empty(B * H * W * Cc, dtype=torch.float32, device=DEV)
+    handle.check(L.lib.rtn_maxpool3x3s2_tfsame_bwd(handle.raw, xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), code, B, H, W, Cc, scratch.data_ptr(), 1))
+    torch.cuda.synchronize()
+    assert float((dx.cpu().double() - want).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("fwd", ["f32", "bf16"])
+def test_adam_clipnorm_matches_keras_formula(pkg, handle, fwd):
+    L = pkg._lib
+    n = 100003
+    g = torch.Generator().manual_seed(5)
+    w0 = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g) * 0.01
+    gscale = torch.rand(n, generator=g) + 0.5
+    gscale[::17] = 0.0                                   # frozen / structurally-zero slots
+    fold = torch.rand(n, generator=g) + 0.5
+    lr, b1, b2, eps, clipnorm, gm = 1e-4, 0.9, 0.999, 1e-7, 0.001, 0.5
+    wd, md, vd = w0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    gd, gsd, fd = grad.to(DEV), gscale.to(DEV), fold.to(DEV)
+    tdt, code = DT[fwd]
+    wf = torch.empty(n, dtype=tdt, device=DEV)
+    ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+    wsb = L.lib.rtn_sumsq_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    # float64 restatement of keras.optimizers.Adam.get_updates + clip_norm (global norm)
+    w, m, v = w0.double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for step in (1, 2, 3):
+        handle.check(L.lib.rtn_sumsq(handle.raw, gd.data_ptr(), gsd.data_ptr(), n, ss.data_ptr(), ws.data_ptr(), wsb))
+        handle.check(L.lib.rtn_adam_clipnorm_step(handle.raw, wd.data_ptr(), md.data_ptr(), vd.data_ptr(), gd.data_ptr(), gsd.data_ptr(),
+                                                  fd.data_ptr(), wf.data_ptr(), code, n, step, lr, b1, b2, eps, ss.data_ptr(), clipnorm, gm))
+        ge = grad.double() * gscale.double() * gm
+        norm = float(torch.sqrt((ge ** 2).sum()))
+        assert abs(float(ss.item()) - float(((grad.double() * gscale.double()) ** 2).sum())) <= 1e-6 * float(ss.item())
+        if norm > clipnorm:
+            ge = ge * (clipnorm / norm)
+        lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        m = b1 * m + (1 - b1) * ge
+        v = b2 * v + (1 - b2) * ge ** 2
+        w = w - lr_t * m / (torch.sqrt(v) + eps)
+    torch.cuda.synchronize()
+    assert float((wd.cpu().double() - w).abs().max()) <= 2e-6
+    assert torch.equal(wd.cpu()[::17], w0[::17])                                   # zero-scaled slots never move
+    wantf = (wd.cpu() * fold).to(tdt)
+    assert float((wf.cpu().float() - wantf.float()).abs().max()) <= (1e-6 if fwd == "f32" else 1e-2)
