@@ -157,3 +157,58 @@ class RefNet:
         reg = torch.cat([self.head(f, "pyramid_regression", 4, False) for f in feats], dim=1)
         cls = torch.cat([self.head(f, "pyramid_classification", self.K, True) for f in feats], dim=1)
         return reg, cls
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Training oracle: the same graph under torch autograd + the losses of model/losses.py in torch (float64), and the
+# optimizer of RetinaNet.py:130 restated from keras.optimizers.Adam.get_updates with clipnorm (global norm, Keras 2.x).
+def focal_torch(y_true, y_pred, alpha=0.25, gamma=2.0):
+    """model/losses.py:22-44 (probabilities in, epsilon clip with the float32 constants, see ref_numpy.focal_loss)."""
+    labels, state = y_true[..., :-1], y_true[..., -1]
+    keep = (state != -1).unsqueeze(-1)
+    one = labels == 1
+    af = torch.where(one, torch.full_like(y_pred, alpha), torch.full_like(y_pred, 1 - alpha))
+    fw = torch.where(one, 1 - y_pred, y_pred)
+    lo, hi = float(np.float32(1e-7)), float(np.float32(1) - np.float32(1e-7))
+    pc = torch.clamp(y_pred, lo, hi)
+    bce = -(labels * torch.log(pc) + (1 - labels) * torch.log(1 - pc))
+    total = torch.where(keep, af * fw ** gamma * bce, torch.zeros_like(bce)).sum()
+    return total / max(1.0, float((state == 1).sum()))
+
+
+def smooth_l1_torch(y_true, y_pred, sigma=3.0):
+    """model/losses.py:58-90."""
+    s2 = sigma ** 2
+    pos = y_true[..., 4] == 1
+    d = (y_pred - y_true[..., :4]).abs()
+    terms = torch.where(d < 1.0 / s2, 0.5 * s2 * d ** 2, d - 0.5 / s2)
+    return terms[pos].sum() / max(1.0, float(pos.sum()))
+
+
+def train_step_oracle(state, images_nhwc, regression_batch, labels_batch, backbone="resnet50", num_classes=1,
+                      dtype=torch.float64):
+    """One forward/backward of total = smooth_l1 + focal (RetinaNet.py:125-131). Returns (loss parts, {kernel/bias name: grad})."""
+    net = RefNet(state, backbone, num_classes, dtype=dtype)
+    train = {k: v for k, v in net.s.items() if k.endswith("/kernel") or k.endswith("/bias")}
+    for v in train.values():
+        v.requires_grad_(True)
+    reg, cls = net.forward(images_nhwc)
+    yr = torch.as_tensor(np.asarray(regression_batch)).to(dtype)
+    yl = torch.as_tensor(np.asarray(labels_batch)).to(dtype)
+    l_reg, l_cls = smooth_l1_torch(yr, reg), focal_torch(yl, cls)
+    (l_reg + l_cls).backward()
+    return (float(l_reg), float(l_cls)), {k: v.grad.detach() for k, v in train.items() if v.grad is not None}
+
+
+def adam_clipnorm_oracle(params, grads, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, clipnorm=0.001):
+    """keras.optimizers.Adam with clipnorm: grads scaled by clipnorm/norm when the GLOBAL norm exceeds clipnorm."""
+    norm = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    c = clipnorm / norm if (clipnorm and norm > clipnorm) else 1.0
+    lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    out = {}
+    for k, p in params.items():
+        g = grads[k].double() * c if k in grads else torch.zeros_like(p, dtype=torch.float64)
+        m[k] = b1 * m.get(k, 0) + (1 - b1) * g
+        v[k] = b2 * v.get(k, 0) + (1 - b2) * g * g
+        out[k] = p.double() - lr_t * m[k] / (torch.sqrt(v[k]) + eps)
+    return out, norm

@@ -84,15 +84,32 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def load_state(self, state):
-        """state: Keras-named dict (see weights.py). Packs every conv (BN folded) onto the device."""
+        """state: Keras-named dict (see weights.py). Packs every conv (BN folded) into ONE flat device buffer of
+        forward weights (dtype of the path) and one flat f32 bias buffer; per-layer tensors are views into them, so an
+        optimizer can rewrite all weights with a single kernel (trainer.py)."""
         self.state = state
         self.w = {}
+        self.layout = {}
+        packed, woff, boff = [], 0, 0
         for (name, kh, kw, cin, cout, has_bias, bn) in Wt.conv_layers(self.backbone, self.K, self.A):
             bnp = None if bn is None else [state[bn + s] for s in ("/gamma", "/beta", "/moving_mean", "/moving_variance")]
             bias = state.get(name + "/bias") if has_bias else None
             pack = Wt.pack_stem if name == "conv1" else Wt.pack_conv
-            wk, bk = pack(state[name + "/kernel"], bias, bnp, self.tdt, self.device)
-            self.w[name] = (wk, bk, kh, kw, cin, cout)
+            wk, bk = pack(state[name + "/kernel"], bias, bnp, self.tdt, "cpu")
+            packed.append((name, wk, bk, kh, kw, cin, cout))
+            self.layout[name] = {"woff": woff, "rows": wk.shape[0], "K": wk.shape[1], "boff": boff, "has_bias": has_bias,
+                                 "bn": bn, "kh": kh, "kw": kw, "cin": cin, "cout": cout}
+            woff += wk.numel()
+            boff += bk.numel()
+        self.wflat = torch.empty(woff, dtype=self.tdt, device=self.device)
+        self.bflat = torch.empty(boff, dtype=torch.float32, device=self.device)
+        for (name, wk, bk, kh, kw, cin, cout) in packed:
+            lo = self.layout[name]
+            wv = self.wflat[lo["woff"]:lo["woff"] + wk.numel()].view(wk.shape)
+            bv = self.bflat[lo["boff"]:lo["boff"] + bk.numel()]
+            wv.copy_(wk)
+            bv.copy_(bk)
+            self.w[name] = (wv, bv, kh, kw, cin, cout)
         self.plans = {}
 
     # ------------------------------------------------------------------ descriptors
@@ -111,9 +128,11 @@ class Engine:
             g.res_img_stride = res.numel() // B
             g.res_ld = res.shape[3]
             g.Hres, g.Wres = (res.shape[1], res.shape[2]) if res_hw is None else res_hw
+        g._x, g._out, g._res, g._off = x, out, res, out_off       # python-side refs for the backward graph
         return g
 
-    def _conv(self, name, groups, B, stride=1, pad=(0, 0), flags=0, out_ld=None, rtn_dtype=None):
+    def _conv(self, name, groups, B, stride=1, pad=(0, 0), flags=0, out_ld=None):
+        """One fused conv launch; the torch tensors behind the groups are kept in the op's meta for the backward graph."""
         wk, bk, kh, kw, cin, cout = self.w[name]
         d = L.ConvDesc()
         for i, g in enumerate(groups):
@@ -126,7 +145,11 @@ class Engine:
         d.pad_t, d.pad_l = pad
         d.out_ld = cout if out_ld is None else out_ld
         d.flags = flags
-        return ("conv", d, name)
+        meta = {"name": name, "xs": [g._x for g in groups], "ys": [g._out for g in groups], "res": [g._res for g in groups],
+                "offs": [g._off for g in groups], "stride": stride, "pad": pad, "flags": flags,
+                "relu": bool(flags & L.CONV_RELU), "kh": kh, "kw": kw, "cin": cin, "cout": cout, "B": B,
+                "out_ld": d.out_ld}
+        return ("conv", d, name, meta)
 
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W):
@@ -168,7 +191,9 @@ class Engine:
         d.pad_t = d.pad_l = 0
         d.out_ld, d.flags = 64, L.CONV_RELU
         ops.append(("pack", xp, xin))
-        ops.append(("conv", d, "conv1"))
+        ops.append(("conv", d, "conv1", {"name": "conv1", "xs": [xp], "ys": [c1], "res": [None], "offs": [0], "stride": 2,
+                                          "pad": (0, 0), "flags": L.CONV_RELU, "relu": True, "kh": 8, "kw": 1, "cin": 32,
+                                          "cout": 64, "B": B, "out_ld": 64, "stem": True}))
         # ---- pool1
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = buf(B, H2, W2, 64)

@@ -1,0 +1,134 @@
+"""GPU parity of one whole training step (forward -> focal + smooth-L1 -> backward through heads/FPN/ResNet-50 ->
+global-norm clip + Adam) against torch-CPU float64 autograd of the restated graph (oracle/ref_net.py; parity unpinned).
+
+fp32 path : per-layer weight gradients within 2e-3 of the layer's gradient scale (max |g|), losses within 1e-5 relative,
+            updated weights within 1e-6 after the Adam step.
+bf16 path : gradient direction — cosine similarity with the float64 gradient >= 0.98 per layer, norms within 10 %."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as R
+from oracle.ref_net import train_step_oracle, adam_clipnorm_oracle
+
+pytestmark = pytest.mark.gpu
+CANVAS = (128, 192)
+LAYERS = ["conv1", "res2a_branch2a", "res2a_branch1", "res2b_branch2b", "res2c_branch2c", "res3a_branch2a", "res3a_branch1",
+          "res3d_branch2b", "res4a_branch1", "res4f_branch2c", "res5a_branch2a", "res5c_branch2b", "C5_reduced", "P5", "C4_reduced",
+          "P4", "C3_reduced", "P3", "P6", "P7", "pyramid_regression_0", "pyramid_regression_3", "pyramid_regression",
+          "pyramid_classification_0", "pyramid_classification_2", "pyramid_classification"]
+
+
+def mods(pkg):
+    return [importlib.import_module(pkg.__name__ + "." + m) for m in ("engine", "weights", "trainer")]
+
+
+def make_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.clamp(torch.empty(B, CANVAS[0], CANVAS[1], 3).exponential_(1 / 12.0, generator=g) *
+                      torch.rand(B, CANVAS[0], CANVAS[1], 3, generator=g), 0, 255).round().to(torch.uint8)
+    x = R.preprocess_custom_tf(raw.numpy())
+    anchors = R.anchors_for_shape(CANVAS + (3,))
+    rng = np.random.RandomState(seed)
+    gts, shapes = [], []
+    for _ in range(B):
+        n = rng.randint(1, 4)
+        w, h = rng.uniform(30, 120, n), rng.uniform(25, 90, n)
+        x1, y1 = rng.uniform(0, CANVAS[1] - w), rng.uniform(0, CANVAS[0] - h)
+        gts.append(np.stack([x1, y1, x1 + w, y1 + h], axis=1))
+        shapes.append((CANVAS[0], int(rng.randint(150, CANVAS[1] + 1))))
+    reg, lab = R.anchor_targets(anchors, shapes, gts, [np.zeros(len(g_)) for g_ in gts], 1)
+    assert (lab[..., 1] == 1).sum() > 10
+    return x, reg, lab
+
+
+def unpack_grad(tr, Wt, name):
+    """flat packed gradient of the folded weights -> gradient w.r.t. the Keras HWIO kernel (x fold scale)."""
+    lo = tr.eng.layout[name]
+    dW, db = tr.grad_views(name)
+    gs = tr.gscale[lo["woff"]:lo["woff"] + lo["rows"] * lo["K"]].view(lo["rows"], lo["K"])
+    g = (dW * gs).cpu().double()
+    cout = lo["cout"]
+    if name == "conv1":
+        k = g[:cout].reshape(cout, 8, 8, 4)[:, :7, :7, :3].permute(1, 2, 3, 0)
+    else:
+        k = g[:cout].reshape(cout, lo["kh"], lo["kw"], lo["cin"]).permute(1, 2, 3, 0)
+    return k, db[:cout].cpu().double()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_step(pkg, dtype):
+    E, Wt, T = mods(pkg)
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    x, reg_t, lab_t = make_batch(2, seed=11)
+    (l_reg, l_cls), og = train_step_oracle(state, x, reg_t, lab_t)
+    eng = E.Engine("resnet50", 1, 9, dtype=dtype)
+    eng.load_state(state)
+    tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001)
+    xd = torch.as_tensor(x).cuda()
+    regd, labd = torch.as_tensor(reg_t).cuda(), torch.as_tensor(lab_t).cuda()
+    sums = tr.forward_backward(xd, regd, labd)
+    torch.cuda.synchronize()
+    s = sums.cpu().numpy()
+    got_reg, got_cls = s[1] / max(1, s[3]), s[0] / max(1, s[2])
+    ltol = 1e-5 if dtype == "f32" else 3e-2
+    assert abs(got_reg - l_reg) <= ltol * abs(l_reg) and abs(got_cls - l_cls) <= ltol * abs(l_cls), (got_reg, l_reg, got_cls, l_cls)
+    worst = (0, "")
+    for name in LAYERS:
+        gk, gb = unpack_grad(tr, Wt, name)
+        want = og[name + "/kernel"].double()
+        scale = float(want.abs().max())
+        if dtype == "f32":
+            err = float((gk - want).abs().max()) / scale
+            worst = max(worst, (err, name))
+            assert err <= 2e-3, "%s: weight-gradient error %.3e of scale %.3e" % (name, err, scale)
+            if name + "/bias" in og:
+                wb = og[name + "/bias"].double()
+                assert float((gb - wb).abs().max()) <= 2e-3 * float(wb.abs().max()), name
+        else:
+            cos = float((gk * want).sum() / (gk.norm() * want.norm()))
+            ratio = float(gk.norm() / want.norm())
+            worst = max(worst, (1 - cos, name))
+            assert cos >= 0.98 and 0.9 <= ratio <= 1.1, "%s: cos %.4f norm ratio %.3f" % (name, cos, ratio)
+    print("%s path: worst layer %s (%.3e)" % (dtype, worst[1], worst[0]))
+    if dtype != "f32":
+        return
+    # ---- optimizer: one global-norm-clipped Adam step against the float64 restatement
+    params = {k: torch.as_tensor(np.asarray(v)) for k, v in state.items() if k.endswith("/kernel") or k.endswith("/bias")}
+    new, norm = adam_clipnorm_oracle(params, og, {}, {}, 1)
+    tr.optimizer_step()
+    torch.cuda.synchronize()
+    got_norm = float(torch.sqrt(tr.sumsq).item())
+    assert abs(got_norm - norm) <= 2e-3 * norm, (got_norm, norm)
+    for name in LAYERS:
+        lo = eng.layout[name]
+        wm = tr.master[lo["woff"]:lo["woff"] + lo["rows"] * lo["K"]].view(lo["rows"], lo["K"]).cpu().double()
+        cout = lo["cout"]
+        if name == "conv1":
+            k = wm[:cout].reshape(cout, 8, 8, 4)[:, :7, :7, :3].permute(1, 2, 3, 0)
+        else:
+            k = wm[:cout].reshape(cout, lo["kh"], lo["kw"], lo["cin"]).permute(1, 2, 3, 0)
+        want = new[name + "/kernel"]
+        # Adam's first step moves every weight by ~lr: compare the MOVE, it is what the optimizer computes
+        move_got, move_want = k - params[name + "/kernel"].double(), want - params[name + "/kernel"].double()
+        assert float((move_got - move_want).abs().max()) <= 0.05 * 1e-4, name
+    # forward weights were re-emitted: a second forward differs from the first
+    reg2, _ = eng.forward(xd)
+    torch.cuda.synchronize()
+    assert torch.isfinite(reg2).all()
+
+
+def test_loss_decreases_over_steps(pkg):
+    """Ten bf16 steps on one fixed batch: the total loss goes down (sanity of the whole loop incl. weight re-emission)."""
+    E, Wt, T = mods(pkg)
+    state = Wt.init_state("resnet50", 1, 9, seed=1, randomize_bn=True, cls_bias=-2.0, tame=True)
+    x, reg_t, lab_t = make_batch(2, seed=5)
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.load_state(state)
+    tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001)
+    xd, regd, labd = torch.as_tensor(x).cuda(), torch.as_tensor(reg_t).cuda(), torch.as_tensor(lab_t).cuda()
+    losses = [tr.train_on_batch(xd, regd, labd)[0] for _ in range(10)]
+    print("losses:", ["%.4f" % v for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
