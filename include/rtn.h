@@ -157,6 +157,12 @@ int rtn_upsample_add_bwd(rtn_handle_t h, const void* d_dst, void* d_src, int dty
 int rtn_maxpool3x3s2_tfsame_bwd(rtn_handle_t h, const void* x, const void* dy, void* dx, int dtype, int B, int Hin, int Win,
                                 int C, float* scratch_f32, int relu_mask /* also zero dx where x <= 0 (x is a ReLU output) */);
 
+/* Training-mode pool1: the forward also records the winning tap (kh*3+kw, first maximum in scan order) per output element
+ * (idx: B*Hout*Wout*C bytes) and the backward is an atomic-free gather over the <= 4 windows that contain an input pixel. */
+int rtn_maxpool3x3s2_tfsame_fwd_idx(rtn_handle_t h, const void* in, void* out, uint8_t* idx, int dtype, int B, int Hin, int Win, int C);
+int rtn_maxpool3x3s2_tfsame_bwd_idx(rtn_handle_t h, const void* dy, const uint8_t* idx, const void* x, void* dx, int dtype,
+                                    int B, int Hin, int Win, int C, int relu_mask);
+
 /* ---- optimizer: Adam(lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=0.001)  (RetinaNet.py:130) ---------------
  * Parameters live in ONE flat f32 buffer (forward weight layout per layer).  gscale[i] multiplies the raw gradient
  * (frozen-BN fold factor of the layer's output channel; 0 for structurally-zero slots), fold[i] re-creates the forward

@@ -76,6 +76,8 @@ SIGNATURES = {
     "rtn_zero_insert2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_upsample_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_maxpool3x3s2_tfsame_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
+    "rtn_maxpool3x3s2_tfsame_fwd_idx": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "rtn_maxpool3x3s2_tfsame_bwd_idx": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "rtn_sumsq_workspace_bytes": (_SZ, []),
     "rtn_sumsq": (_I, [_P, _P, _P, _I64, _P, _P, _SZ]),
     "rtn_adam_clipnorm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _F, _F, _F, _F, _P, _F, _F]),

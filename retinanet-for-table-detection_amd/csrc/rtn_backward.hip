@@ -232,33 +232,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
 template <int ES>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const char* __restrict__ dy, long long rows, int N, long long ld_b,
                                                         float* __restrict__ db) {
-    // thread = one 16-byte chunk column, strided over rows; partial sums combined with one atomic per chunk element
+    // thread = (16-byte chunk column c, row lane r); rows are strided over row lanes and blocks; the row lanes of a block are
+    // summed through LDS so that each block issues ONE atomic per channel (same-address atomics serialise).
     constexpr int CE = 16 / ES;
+    __shared__ float sh[256 * CE];
     const int nch = (N + CE - 1) / CE;
-    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) % nch;
-    const long long rstart = (blockIdx.x * (long long)blockDim.x + threadIdx.x) / nch;
-    const long long rstride = ((long long)gridDim.x * blockDim.x) / nch;
-    if (rstride == 0 || rstart >= rstride) return;      // leftover threads would double-count row class 0
+    const int RP = 256 / nch;                          // row lanes per block (host guarantees nch <= 256)
+    const int c = threadIdx.x % nch, r = threadIdx.x / nch;
     float s[CE];
 #pragma unroll
     for (int j = 0; j < CE; ++j) s[j] = 0.f;
-    for (long long r = rstart; r < rows; r += rstride) {
-        const uint4 q = *reinterpret_cast<const uint4*>(dy + r * ld_b + (long long)chunk * 16);
-        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
-        if constexpr (ES == 2) {
+    if (r < RP) {
+        for (long long row = (long long)blockIdx.x * RP + r; row < rows; row += (long long)gridDim.x * RP) {
+            const uint4 q = *reinterpret_cast<const uint4*>(dy + row * ld_b + (long long)c * 16);
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+            if constexpr (ES == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[2 * j] += __uint_as_float(w4[j] << 16);
-                s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                for (int j = 0; j < 4; ++j) {
+                    s[2 * j] += __uint_as_float(w4[j] << 16);
+                    s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < CE; ++j)
-        if (chunk * CE + j < N) unsafeAtomicAdd(db + chunk * CE + j, s[j]);
+    for (int j = 0; j < CE; ++j) sh[threadIdx.x * CE + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < nch) {
+#pragma unroll
+        for (int j = 0; j < CE; ++j) {
+            float v = 0.f;
+            for (int rr = 0; rr < RP; ++rr) v += sh[(threadIdx.x + rr * nch) * CE + j];
+            if (threadIdx.x * CE + j < N) unsafeAtomicAdd(db + threadIdx.x * CE + j, v);
+        }
+    }
 }
 
 // out[b][2*oy][2*ox][:] = in[b][oy][ox][:], zeros elsewhere; out is [B][Hu][Wu][C]
@@ -340,6 +350,141 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const char* __res
             o = make_uint4(__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3]));
         }
         *reinterpret_cast<uint4*>(op) = o;
+    }
+}
+
+// Training-mode max-pool: also records which of the 9 window taps (kh*3+kw, first maximum in scan order — TF MaxPoolGrad's
+// choice) won, one byte per output element, so that the backward pass is a gather with no atomics.
+template <int ES>
+__global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const char* __restrict__ in, char* __restrict__ out,
+                                                              unsigned char* __restrict__ idx, int B, int Hin, int Win, int C, int Hout,
+                                                              int Wout, int pad_t, int pad_l) {
+    constexpr int CE = 16 / ES;
+    const int cv = C / CE;
+    const long long total = (long long)B * Hout * Wout * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv);
+        long long r = i / cv;
+        const int ox = (int)(r % Wout);
+        r /= Wout;
+        const int oy = (int)(r % Hout);
+        const int b = (int)(r / Hout);
+        float mx[CE];
+        unsigned char am[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) { mx[j] = -INFINITY; am[j] = 255; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - pad_t + kh;
+            if ((unsigned)iy >= (unsigned)Hin) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - pad_l + kw;
+                if ((unsigned)ix >= (unsigned)Win) continue;
+                const uint4 q = *reinterpret_cast<const uint4*>(in + ((((long long)b * Hin + iy) * Win + ix) * C + cc * CE) * ES);
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                float v[CE];
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w4[j] << 16); v[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(w4[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < CE; ++j)
+                    if (v[j] > mx[j]) { mx[j] = v[j]; am[j] = (unsigned char)(kh * 3 + kw); }
+            }
+        }
+        uint4 o;
+        if constexpr (ES == 2) {
+            o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+            o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+            o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+            o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+        } else {
+            o = make_uint4(__float_as_uint(mx[0]), __float_as_uint(mx[1]), __float_as_uint(mx[2]), __float_as_uint(mx[3]));
+        }
+        *reinterpret_cast<uint4*>(out + i * 16) = o;
+#pragma unroll
+        for (int j = 0; j < CE; ++j) idx[i * CE + j] = am[j];
+    }
+}
+
+// dx[b][iy][ix][c] = sum over the (at most 4) windows containing (iy,ix) whose recorded winner is this tap of dy,
+// zeroed where x <= 0 when relu_mask (x is a ReLU output).
+template <int ES>
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const char* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                              const char* __restrict__ x, char* __restrict__ dx, int B, int Hin, int Win,
+                                                              int C, int Hout, int Wout, int pad_t, int pad_l, int relu_mask) {
+    constexpr int CE = 16 / ES;
+    const int cv = C / CE;
+    const long long total = (long long)B * Hin * Win * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cv);
+        long long r = i / cv;
+        const int ix = (int)(r % Win);
+        r /= Win;
+        const int iy = (int)(r % Hin);
+        const int b = (int)(r / Hin);
+        float s[CE];
+#pragma unroll
+        for (int j = 0; j < CE; ++j) s[j] = 0.f;
+        // windows oy with oy*2 - pad_t <= iy <= oy*2 - pad_t + 2
+        const int ty = iy + pad_t, tx = ix + pad_l;
+        for (int oy = (ty - 2 + 1) >> 1; oy <= (ty >> 1); ++oy) {
+            if (oy < 0 || oy >= Hout) continue;
+            const int kh = ty - 2 * oy;
+            for (int ox = (tx - 2 + 1) >> 1; ox <= (tx >> 1); ++ox) {
+                if (ox < 0 || ox >= Wout) continue;
+                const int kw = tx - 2 * ox;
+                const unsigned char tap = (unsigned char)(kh * 3 + kw);
+                const long long o = (((long long)b * Hout + oy) * Wout + ox) * cv + cc;
+                const uint4 gq = *reinterpret_cast<const uint4*>(dy + o * 16);
+                const unsigned g4[4] = {gq.x, gq.y, gq.z, gq.w};
+                const unsigned char* ip = idx + o * CE;
+                if constexpr (ES == 2) {
+                    const uint2 iq = *reinterpret_cast<const uint2*>(ip);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned char a = (unsigned char)(((j < 4 ? iq.x : iq.y) >> (8 * (j & 3))) & 0xffu);
+                        const float g = (j & 1) ? __uint_as_float(g4[j >> 1] & 0xffff0000u) : __uint_as_float(g4[j >> 1] << 16);
+                        if (a == tap) s[j] += g;
+                    }
+                } else {
+                    const unsigned iq = *reinterpret_cast<const unsigned*>(ip);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((unsigned char)((iq >> (8 * j)) & 0xffu) == tap) s[j] += __uint_as_float(g4[j]);
+                }
+            }
+        }
+        if (relu_mask) {
+            const uint4 xq = *reinterpret_cast<const uint4*>(x + i * 16);
+            const unsigned x4[4] = {xq.x, xq.y, xq.z, xq.w};
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xv = (j & 1) ? __uint_as_float(x4[j >> 1] & 0xffff0000u) : __uint_as_float(x4[j >> 1] << 16);
+                    if (!(xv > 0.f)) s[j] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(__uint_as_float(x4[j]) > 0.f)) s[j] = 0.f;
+            }
+        }
+        uint4 o;
+        if constexpr (ES == 2) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bf16x2 v = {(__bf16)s[2 * j], (__bf16)s[2 * j + 1]}; w[j] = __builtin_bit_cast(unsigned, v); }
+            o = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            o = make_uint4(__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3]));
+        }
+        *reinterpret_cast<uint4*>(dx + i * 16) = o;
     }
 }
 
@@ -615,11 +760,11 @@ extern "C" int rtn_bias_grad(rtn_handle_t h, const void* dy, int dtype, int64_t 
     if ((ld * es) % 16 || ((uintptr_t)dy & 15)) return rtn_fail(h, RTN_EINVAL, "bias_grad: ld/pointer not 16-byte aligned");
     const int ce = 16 / es, nch = (N + ce - 1) / ce;
     if ((long long)nch * ce > ld) return rtn_fail(h, RTN_EINVAL, "bias_grad: last chunk leaves the row");
-    long long threads = (long long)nch * ((rows + 63) / 64);
-    if (threads < nch) threads = nch;
-    long long blocks = (threads + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    // the kernel needs gridDim*256 to be a multiple of nch-aligned strides: rstride = total/nch (floor) is fine
+    if (nch > 256) return rtn_fail(h, RTN_EINVAL, "bias_grad: N %d too wide", N);
+    const int rp = 256 / nch;
+    long long blocks = (rows + (long long)rp * 32 - 1) / ((long long)rp * 32);     // ~32 rows per row lane
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
     if (es == 2) hipLaunchKernelGGL((bias_grad_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (const char*)dy, (long long)rows, N, (long long)ld * es, db);
     else         hipLaunchKernelGGL((bias_grad_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (const char*)dy, (long long)rows, N, (long long)ld * es, db);
     RTN_CHECK_LAUNCH(h, "bias_grad_kernel");
@@ -715,5 +860,39 @@ extern "C" int rtn_pad_cast_rows(rtn_handle_t h, const float* in, void* out, int
     if (dtype == RTN_BF16) hipLaunchKernelGGL((pad_cast_rows_kernel<2>), dim3(nb), dim3(256), 0, h->stream, in, (char*)out, (long long)rows, cin, cout);
     else                   hipLaunchKernelGGL((pad_cast_rows_kernel<4>), dim3(nb), dim3(256), 0, h->stream, in, (char*)out, (long long)rows, cin, cout);
     RTN_CHECK_LAUNCH(h, "pad_cast_rows_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_maxpool3x3s2_tfsame_fwd_idx(rtn_handle_t h, const void* in, void* out, uint8_t* idx, int dtype, int B, int Hin,
+                                               int Win, int C) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || !idx || B < 1 || Hin < 1 || Win < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "maxpool_fwd_idx: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "maxpool_fwd_idx: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)idx & 7)) return rtn_fail(h, RTN_EINVAL, "maxpool_fwd_idx: alignment");
+    const int Hout = (Hin + 1) / 2, Wout = (Win + 1) / 2;
+    int pth = (Hout - 1) * 2 + 3 - Hin; if (pth < 0) pth = 0;
+    int ptw = (Wout - 1) * 2 + 3 - Win; if (ptw < 0) ptw = 0;
+    const long long total = (long long)B * Hout * Wout * (C * es / 16);
+    if (es == 2) hipLaunchKernelGGL((maxpool_fwd_idx_kernel<2>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)in, (char*)out, idx, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    else         hipLaunchKernelGGL((maxpool_fwd_idx_kernel<4>), dim3(grid_for(total)), dim3(256), 0, h->stream, (const char*)in, (char*)out, idx, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2);
+    RTN_CHECK_LAUNCH(h, "maxpool_fwd_idx_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_maxpool3x3s2_tfsame_bwd_idx(rtn_handle_t h, const void* dy, const uint8_t* idx, const void* x, void* dx, int dtype,
+                                               int B, int Hin, int Win, int C, int relu_mask) {
+    if (!h) return RTN_EINVAL;
+    if (!dy || !idx || !dx || (relu_mask && !x) || B < 1 || Hin < 1 || Win < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd_idx: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd_idx: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)x & 15) || ((uintptr_t)idx & 7)) return rtn_fail(h, RTN_EINVAL, "maxpool_bwd_idx: alignment");
+    const int Hout = (Hin + 1) / 2, Wout = (Win + 1) / 2;
+    int pth = (Hout - 1) * 2 + 3 - Hin; if (pth < 0) pth = 0;
+    int ptw = (Wout - 1) * 2 + 3 - Win; if (ptw < 0) ptw = 0;
+    const long long total = (long long)B * Hin * Win * (C * es / 16);
+    if (es == 2) hipLaunchKernelGGL((maxpool_bwd_idx_kernel<2>), dim3(grid_for(total, 8192)), dim3(256), 0, h->stream, (const char*)dy, idx, (const char*)x, (char*)dx, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2, relu_mask);
+    else         hipLaunchKernelGGL((maxpool_bwd_idx_kernel<4>), dim3(grid_for(total, 8192)), dim3(256), 0, h->stream, (const char*)dy, idx, (const char*)x, (char*)dx, B, Hin, Win, C, Hout, Wout, pth / 2, ptw / 2, relu_mask);
+    RTN_CHECK_LAUNCH(h, "maxpool_bwd_idx_kernel");
     return RTN_OK;
 }

@@ -81,6 +81,7 @@ class Engine:
         self.w = {}
         self.plans = {}
         self.state = None
+        self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
 
     # ------------------------------------------------------------------ weights
     def load_state(self, state):
@@ -197,7 +198,9 @@ class Engine:
         # ---- pool1
         H2, W2 = (H1 + 1) // 2, (W1 + 1) // 2
         x = buf(B, H2, W2, 64)
-        ops.append(("pool", c1, x, (B, H1, W1, 64)))
+        pool_idx = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)     # winning taps (training mode only)
+        keep.append(pool_idx)
+        ops.append(("pool", c1, x, (B, H1, W1, 64), pool_idx))
         # ---- bottleneck stages
         feats = []
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
@@ -310,7 +313,10 @@ class Engine:
                                       xi["B"], xi["H"], xi["W"], xi["Hp"], xi["Wp"]))
         elif kind == "pool":
             Bn, Hi, Wi, Cc = op[3]
-            h.check(lib.rtn_maxpool3x3s2_tfsame_fwd(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
+            if self.training:
+                h.check(lib.rtn_maxpool3x3s2_tfsame_fwd_idx(h.raw, op[1].data_ptr(), op[2].data_ptr(), op[4].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
+            else:
+                h.check(lib.rtn_maxpool3x3s2_tfsame_fwd(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, Bn, Hi, Wi, Cc))
         elif kind == "relu":
             h.check(lib.rtn_relu(h.raw, op[1].data_ptr(), op[2].data_ptr(), self.rdt, op[1].numel()))
         else:

@@ -310,9 +310,7 @@ class Trainer:
                 x, y = op[1], op[2]
                 dy = grads.get(tid(y))
                 done[tid(x)] = done.get(tid(x), 0) + 1
-                scratch = torch.empty(x.numel(), dtype=torch.float32, device=dev)
-                keep.append(scratch)
-                bops.append(("poolbwd", x, dy, gbuf(x), op[3], scratch))
+                bops.append(("poolbwd", x, dy, gbuf(x), op[3], op[4]))
                 gstate[tid(x)] = "buf"
         ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
@@ -327,7 +325,11 @@ class Trainer:
         eng, lib = self.eng, L.lib
         h = eng.h
         B, H, W, _ = images.shape
-        reg, cls = eng.forward(images)
+        eng.training = True
+        try:
+            reg, cls = eng.forward(images)
+        finally:
+            eng.training = False
         bp = self._bplan(B, H, W)
         N, K = bp["plan"]["N"], eng.K
         rows = B * N
@@ -363,8 +365,8 @@ class Trainer:
                 h.check(lib.rtn_upsample_add_bwd(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, Bn, Hd, Wd, Hs, Ws, Cc, b[4]))
             elif kind == "poolbwd":
                 Bn, Hi, Wi, Cc = b[4]
-                h.check(lib.rtn_maxpool3x3s2_tfsame_bwd(h.raw, b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), eng.rdt, Bn, Hi, Wi,
-                                                        Cc, b[5].data_ptr(), 1))
+                h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), b[1].data_ptr(), b[3].data_ptr(), eng.rdt,
+                                                            Bn, Hi, Wi, Cc, 1))
             else:
                 raise RuntimeError(kind)
         return self.loss_sums

@@ -259,6 +259,15 @@ def test_maxpool_bwd(pkg, handle, dtype):
     handle.check(L.lib.rtn_maxpool3x3s2_tfsame_bwd(handle.raw, xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), code, B, H, W, Cc, scratch.data_ptr(), 1))
     torch.cuda.synchronize()
     assert float((dx.cpu().double() - want).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(want.abs().max()))
+    # training-mode pair: forward records the winning tap, backward is an atomic-free gather — same answers
+    yd = torch.empty(B, Ho, Wo, Cc, dtype=tdt, device=DEV)
+    idx = torch.empty(B * Ho * Wo * Cc, dtype=torch.uint8, device=DEV)
+    handle.check(L.lib.rtn_maxpool3x3s2_tfsame_fwd_idx(handle.raw, xd.data_ptr(), yd.data_ptr(), idx.data_ptr(), code, B, H, W, Cc))
+    dx2 = torch.full_like(xd, 3.0)
+    handle.check(L.lib.rtn_maxpool3x3s2_tfsame_bwd_idx(handle.raw, dyd.data_ptr(), idx.data_ptr(), xd.data_ptr(), dx2.data_ptr(), code, B, H, W, Cc, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(yd.cpu().double(), y.detach())
+    assert float((dx2.cpu().double() - want).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("fwd", ["f32", "bf16"])
