@@ -75,12 +75,89 @@ def cpu_baseline(torch, state, threads):
             "sample": "%d x (1 image 800x1333: fp32 torch-CPU forward + NumPy decode/NMS), %.1f s" % (n, dt)}
 
 
+TRAIN_BATCH = 16                   # BASELINE.json configs[2]: batch 16 per GPU
+TRAIN_GFLOP_PER_IMAGE = 1248.4     # ~3x forward (dgrad + wgrad for every conv)
+
+
+def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
+    """One step = forward + focal/smooth-L1 + backward + (bucketed RCCL all-reduce under DP) + clipnorm Adam on a batch of
+    16 synthetic pages per GPU; anchor targets are produced on the device by rtn_anchor_targets inside the timed region."""
+    import ctypes as C
+    import numpy as np
+    T = importlib.import_module(PKG + ".trainer")
+    L = importlib.import_module(PKG + "._lib")
+    B = TRAIN_BATCH
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16", device=local_rank)
+    eng.load_state(state)
+    tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001, process_group=(dist.group.WORLD if dist is not None else None))
+    x = synth_images(torch, B, 2000 + rank, device)
+    cfg, N = E.make_anchor_cfg(CANVAS)
+    rng = np.random.RandomState(100 + rank)
+    gb, gc = np.zeros((B, 64, 4)), np.zeros(B, np.int32)
+    for b in range(B):                                  # SURVEY §8d config 3: 1-6 boxes, w,h in [80,900]x[60,600]
+        g = rng.randint(1, 7)
+        w, h = rng.uniform(80, 900, g), rng.uniform(60, 600, g)
+        x1, y1 = rng.uniform(0, CANVAS[1] - w), rng.uniform(0, CANVAS[0] - h)
+        gb[b, :g] = np.stack([x1, y1, x1 + w, y1 + h], 1)
+        gc[b] = g
+    gbd, gld, gcd = torch.as_tensor(gb).to(device), torch.zeros(B, 64, dtype=torch.int32, device=device), torch.as_tensor(gc).to(device)
+    hw = torch.as_tensor(np.tile(np.array(CANVAS, np.int32), (B, 1))).to(device)
+    reg_t = torch.empty(B, N, 5, device=device)
+    lab_t = torch.empty(B, N, 2, device=device)
+
+    def step():
+        eng._bind_stream()
+        eng.h.check(L.lib.rtn_anchor_targets(eng.h.raw, C.byref(cfg), B, 1, gbd.data_ptr(), gld.data_ptr(), gcd.data_ptr(), hw.data_ptr(),
+                                             0.4, 0.5, reg_t.data_ptr(), lab_t.data_ptr()))
+        tr.forward_backward(x, reg_t, lab_t)
+        tr.optimizer_step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        s = tr.norm_sums.cpu().numpy()
+        achieved = value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world
+        print(json.dumps({"metric": "images/sec RetinaNet R50-FPN 800x1333 training step", "value": value, "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "ResNet50-FPN RetinaNet training step 800x1333 bf16 batch 16/GPU: targets + fwd + "
+                                                 "focal/smooth-L1 + bwd + clipnorm Adam (BASELINE.json configs[2]/[3])",
+                                     "batch_per_gpu": B, "positives_merged_batch": float(s[2]),
+                                     "parallelism": "dp%d (bucketed gradient all-reduce overlapped with backward)" % world},
+                          "roofline": {"bound": "mfma", "kernel": "conv fwd+dgrad+wgrad (whole step)", "achieved": achieved,
+                                       "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
+                                       "traffic": None},
+                          "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer (default, BASELINE.json configs[1]) or train (configs[2]/[3]: batch 16/GPU training step)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +175,8 @@ def main():
 
     E = importlib.import_module(PKG + ".engine")
     Wt = importlib.import_module(PKG + ".weights")
+    if args.mode == "train":
+        return bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device)
     x = synth_images(torch, BATCH, 1000 + rank, device)
     eng = E.Engine("resnet50", 1, 9, dtype="bf16", device=local_rank)
     # calibration (untimed): choose the classification bias so that CAND_FRACTION of the anchors clear the 0.05 score

@@ -23,6 +23,7 @@ import torch
 
 from . import _lib as L
 from . import weights as Wt
+from . import parallel as Par
 
 
 def _ceil128(v):
@@ -39,6 +40,11 @@ class Trainer:
         self.step_count = 0
         self.bplans = {}
         self._init_params()
+        self.bucketer = None
+        if self.pg is not None:
+            segs = [(name, lo["woff"], lo["woff"] + lo["rows"] * lo["K"]) for name, lo in self.eng.layout.items()]
+            segs.append(("__biases__", self.NW, self.NW + self.NB))           # FPN/head biases: one last segment
+            self.bucketer = Par.GradBucketer(self.grad, segs, group=self.pg)
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self):
@@ -339,9 +345,7 @@ class Trainer:
                                         bp["loss_ws"].data_ptr(), bp["loss_ws"].numel()))
         norm = self.loss_sums
         if self.pg is not None:                      # merged-batch normaliser (multi_gpu_model semantics)
-            import torch.distributed as dist
-            norm = self.loss_sums.clone()
-            dist.all_reduce(norm, group=self.pg)
+            norm = Par.allreduce_loss_sums(self.loss_sums, self.pg)
         self.norm_sums = norm
         h.check(lib.rtn_retina_loss_bwd_dev(h.raw, rows, K, labels_batch.data_ptr(), regression_batch.data_ptr(), cls.data_ptr(),
                                             reg.data_ptr(), self.alpha, self.gamma, self.sigma, norm.data_ptr(), 1,
@@ -351,6 +355,8 @@ class Trainer:
             kind = b[0]
             if kind == "wgrad":
                 h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
+                if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
+                    self.bucketer.layer_done(b[3])
             elif kind == "dgrad":
                 h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
             elif kind == "bgrad":
@@ -375,9 +381,8 @@ class Trainer:
         """Global-norm clip + Adam on the flat parameter vector, re-emission of the forward and dgrad weights."""
         eng, lib, h = self.eng, L.lib, self.eng.h
         eng._bind_stream()
-        if self.pg is not None:                      # sum of per-rank gradients == gradient of the merged batch
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, group=self.pg)
+        if self.bucketer is not None:                # sum of per-rank gradients == gradient of the merged batch
+            self.bucketer.finish()
         self.step_count += 1
         n = self.NW + self.NB
         h.check(lib.rtn_sumsq(h.raw, self.grad.data_ptr(), self.gscale.data_ptr(), n, self.sumsq.data_ptr(), self.ss_ws.data_ptr(),
