@@ -231,6 +231,20 @@ int rtn_anchor_targets(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, int n
                        double negative_overlap, double positive_overlap,
                        float* regression_batch, float* labels_batch);
 
+/* Stand-alone pieces of the same path, for callers that use the reference's individual functions:
+ *   rtn_anchor_targets_explicit : anchor_targets_bbox on a caller-supplied anchors array (device f64 [N][4])
+ *   rtn_compute_overlap         : utils.compute_overlap (model/utils.py:180-211) -> f32 [N][G]
+ *   rtn_gt_annotations          : compute_gt_annotations (model/anchors.py:96-117) on that matrix
+ *   rtn_bbox_transform          : bbox_transform (model/anchors.py:282-313), f64 */
+int rtn_anchor_targets_explicit(rtn_handle_t h, const double* anchors, int N, int B, int num_classes, const double* gt_boxes,
+                                const int32_t* gt_labels, const int32_t* gt_count, const int32_t* img_hw,
+                                double negative_overlap, double positive_overlap, float* regression_batch, float* labels_batch);
+int rtn_compute_overlap(rtn_handle_t h, const double* boxes, const double* gts, int N, int G, float* out);
+int rtn_gt_annotations(rtn_handle_t h, const float* overlaps, int N, int G, double negative_overlap, double positive_overlap,
+                       uint8_t* positive, uint8_t* ignore, int64_t* argmax);
+int rtn_bbox_transform(rtn_handle_t h, const double* anchors, const double* gt_boxes, int N, const double* mean4 /* host */,
+                       const double* std4 /* host */, double* out);
+
 /* ---- focal + smooth-L1 (model/losses.py:5-46, 49-91) --------------------------------
  * fwd: sums[0] = sum of focal terms over non-ignored anchors, sums[1] = sum of smooth-L1
  * terms over positive anchors, sums[2] = number of positive anchors (state == 1); the
@@ -277,6 +291,34 @@ int rtn_decode_filter_nms(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, in
                           float score_threshold, float nms_threshold, int max_detections,
                           float* boxes, float* scores, int32_t* labels,
                           void* workspace, size_t workspace_bytes);
+
+/* ---- page preprocessing -------------------------------------------------------------------------------
+ * rtn_preprocess_dt3: DetectTablesUtils.preProcessSampleImages (DetectTablesUtils.py:251-261) for B equally sized pages:
+ *   src uint8 [B][H][W][channels] (3 = BGR as cv2.imread gives, 1 = gray) -> dst uint8 [B][H][W][3] in OpenCV channel order
+ *   b = DIST_L2 (mask 5), g = DIST_L1, r = DIST_C of the Gaussian adaptive threshold (block 11, C 2), saturated like imwrite.
+ *   binary_out (optional, [B][H][W]) receives the thresholded image.  W <= 4096.
+ * rtn_distance_transform3: the three distance transforms + merge + saturate of a caller-provided binary image.
+ * rtn_resize_cubic: utils.resize_image (model/utils.py:140-154) = cv2.resize(INTER_CUBIC) of one HxWxC image; src f32, or
+ *   uint8 with the 'custom_tf' normalisation x/127.5-1 (model/utils.py:43-46) fused; dst f32/bf16 rows dst_row_stride apart,
+ *   i.e. written straight into the zero-padded batch canvas of Generator.compute_inputs (csv_generator.py:320-336). */
+size_t rtn_preprocess_dt3_workspace_bytes(int B, int H, int W);
+int rtn_preprocess_dt3(rtn_handle_t h, const uint8_t* src, int channels, int B, int H, int W, uint8_t* dst, uint8_t* binary_out,
+                       void* workspace, size_t workspace_bytes);
+int rtn_distance_transform3(rtn_handle_t h, const uint8_t* binary, int B, int H, int W, uint8_t* dst, void* workspace,
+                            size_t workspace_bytes);
+int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, int H, int W, int C, double scale, void* dst, int dst_dtype,
+                     int Ho, int Wo, int64_t dst_row_stride);
+
+/* The graph layers as separate calls (model/layers.py): FilterDetections on explicit boxes, RegressBoxes, ClipBoxes,
+ * UpsampleLike; and utils.preprocess_image (model/utils.py:19-47; mode 0 'tf', 1 'caffe', 2 'custom_tf'). */
+int rtn_filter_detections(rtn_handle_t h, int B, int64_t N, int num_classes, const float* in_boxes, const float* classification,
+                          float score_threshold, float nms_threshold, int max_detections, float* boxes, float* scores,
+                          int32_t* labels, void* workspace, size_t workspace_bytes);
+int rtn_regress_boxes(rtn_handle_t h, const float* anchors, const float* deltas, int64_t n_boxes, const float* mean4 /* host */,
+                      const float* std4 /* host */, float* out);
+int rtn_clip_boxes(rtn_handle_t h, const float* in, int64_t n_boxes, float width, float height, float* out);
+int rtn_upsample_nearest(rtn_handle_t h, const void* src, void* dst, int dtype, int B, int Hs, int Ws, int Hd, int Wd, int C);
+int rtn_preprocess_image(rtn_handle_t h, const void* src, int src_dtype, float* dst, int64_t n, int mode, float scale, float sub);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,19 @@ SIGNATURES = {
     "rtn_anchors_f64": (_I, [_P, C.POINTER(AnchorCfg), _P]),
     "rtn_anchors_f32": (_I, [_P, C.POINTER(AnchorCfg), _P]),
     "rtn_anchor_targets": (_I, [_P, C.POINTER(AnchorCfg), _I, _I, _P, _P, _P, _P, _D, _D, _P, _P]),
+    "rtn_anchor_targets_explicit": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _D, _D, _P, _P]),
+    "rtn_compute_overlap": (_I, [_P, _P, _P, _I, _I, _P]),
+    "rtn_gt_annotations": (_I, [_P, _P, _I, _I, _D, _D, _P, _P, _P]),
+    "rtn_bbox_transform": (_I, [_P, _P, _P, _I, C.POINTER(_D), C.POINTER(_D), _P]),
+    "rtn_filter_detections": (_I, [_P, _I, _I64, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _SZ]),
+    "rtn_regress_boxes": (_I, [_P, _P, _P, _I64, C.POINTER(_F), C.POINTER(_F), _P]),
+    "rtn_clip_boxes": (_I, [_P, _P, _I64, _F, _F, _P]),
+    "rtn_upsample_nearest": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "rtn_preprocess_image": (_I, [_P, _P, _I, _P, _I64, _I, _F, _F]),
+    "rtn_preprocess_dt3_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "rtn_preprocess_dt3": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _SZ]),
+    "rtn_distance_transform3": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ]),
+    "rtn_resize_cubic": (_I, [_P, _P, _I, _I, _I, _I, _D, _P, _I, _I, _I, _I64]),
     "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
     "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),
     "rtn_retina_loss_bwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P]),

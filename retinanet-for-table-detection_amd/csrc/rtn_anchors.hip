@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void anchors_f32_kernel(const DevAnchorCfg c, 
 __global__ __launch_bounds__(256) void anchor_targets_kernel(const DevAnchorCfg c, int K, const double* __restrict__ gt_boxes,
                                                              const int* __restrict__ gt_labels, const int* __restrict__ gt_count,
                                                              const int* __restrict__ img_hw, float neg_ov, float pos_ov,
-                                                             float* __restrict__ reg_out, float* __restrict__ lab_out) {
+                                                             float* __restrict__ reg_out, float* __restrict__ lab_out,
+                                                             const double* __restrict__ anchors_explicit, int n_explicit) {
     __shared__ double s_gt[RTN_MAX_GT][4];
     __shared__ double s_area[RTN_MAX_GT];
     __shared__ int s_lab[RTN_MAX_GT];
@@ -92,10 +93,15 @@ __global__ __launch_bounds__(256) void anchor_targets_kernel(const DevAnchorCfg 
     }
     __syncthreads();
     const int img_h = img_hw[2 * b], img_w = img_hw[2 * b + 1];
-    const int N = c.total;
+    const int N = anchors_explicit ? n_explicit : c.total;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
         double a[4];
-        anchor_f64(c, n, a);
+        if (anchors_explicit) {
+            a[0] = anchors_explicit[4ll * n]; a[1] = anchors_explicit[4ll * n + 1];
+            a[2] = anchors_explicit[4ll * n + 2]; a[3] = anchors_explicit[4ll * n + 3];
+        } else {
+            anchor_f64(c, n, a);
+        }
         float state = 0.f;
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         int label = -1;
@@ -178,7 +184,112 @@ extern "C" int rtn_anchor_targets(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, i
     if (gx > 1024) gx = 1024;
     // thresholds compare against a float32 array: NumPy casts the Python float to float32
     hipLaunchKernelGGL(anchor_targets_kernel, dim3(gx, B), dim3(256), 0, h->stream, d, num_classes, gt_boxes, gt_labels,
-                       gt_count, img_hw, (float)negative_overlap, (float)positive_overlap, regression_batch, labels_batch);
+                       gt_count, img_hw, (float)negative_overlap, (float)positive_overlap, regression_batch, labels_batch,
+                       (const double*)nullptr, 0);
     RTN_CHECK_LAUNCH(h, "anchor_targets_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_anchor_targets_explicit(rtn_handle_t h, const double* anchors, int N, int B, int num_classes, const double* gt_boxes,
+                                           const int32_t* gt_labels, const int32_t* gt_count, const int32_t* img_hw,
+                                           double negative_overlap, double positive_overlap, float* regression_batch,
+                                           float* labels_batch) {
+    if (!h) return RTN_EINVAL;
+    if (N < 1 || B < 1 || B > 65535 || num_classes < 1) return rtn_fail(h, RTN_EINVAL, "anchor_targets_explicit: N %d B %d classes %d", N, B, num_classes);
+    if (!anchors || !gt_boxes || !gt_labels || !gt_count || !img_hw || !regression_batch || !labels_batch)
+        return rtn_fail(h, RTN_EINVAL, "anchor_targets_explicit: null pointer");
+    DevAnchorCfg d;
+    memset(&d, 0, sizeof(d));
+    unsigned gx = (unsigned)((N + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(anchor_targets_kernel, dim3(gx, B), dim3(256), 0, h->stream, d, num_classes, gt_boxes, gt_labels, gt_count,
+                       img_hw, (float)negative_overlap, (float)positive_overlap, regression_batch, labels_batch, anchors, N);
+    RTN_CHECK_LAUNCH(h, "anchor_targets_kernel");
+    return RTN_OK;
+}
+
+namespace {
+// model/utils.py:180-211: IoU of every (box, gt) pair, f64 math, f32 result
+__global__ __launch_bounds__(256) void compute_overlap_kernel(const double* __restrict__ boxes, const double* __restrict__ gts, int N,
+                                                              int G, float* __restrict__ out) {
+    const long long total = (long long)N * G;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / G), g = (int)(i - (long long)n * G);
+        const double* a = boxes + 4ll * n;
+        const double* b = gts + 4ll * g;
+        const double area1 = (a[2] - a[0]) * (a[3] - a[1]);
+        const double area2 = (b[2] - b[0]) * (b[3] - b[1]);
+        const double w = fmax(0.0, fmin(a[2], b[2]) - fmax(a[0], b[0]));
+        const double hh = fmax(0.0, fmin(a[3], b[3]) - fmax(a[1], b[1]));
+        const double inter = w * hh;
+        out[i] = (float)(inter / (area1 + area2 - inter));
+    }
+}
+
+// model/anchors.py:96-117 on a precomputed f32 overlap matrix: first-max argmax, >= pos, > neg & !pos
+__global__ __launch_bounds__(256) void gt_annotations_kernel(const float* __restrict__ ov, int N, int G, float neg_ov, float pos_ov,
+                                                             unsigned char* __restrict__ positive, unsigned char* __restrict__ ignore,
+                                                             long long* __restrict__ argmax) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        float best = ov[(long long)n * G];
+        int arg = 0;
+        for (int g = 1; g < G; ++g) {
+            const float v = ov[(long long)n * G + g];
+            if (v > best) { best = v; arg = g; }
+        }
+        const bool pos = best >= pos_ov;
+        positive[n] = pos ? 1 : 0;
+        ignore[n] = (best > neg_ov && !pos) ? 1 : 0;
+        argmax[n] = arg;
+    }
+}
+
+// model/anchors.py:282-313: ((gt - anchor) / anchor extent - mean) / std, f64
+__global__ __launch_bounds__(256) void bbox_transform_kernel(const double* __restrict__ anchors, const double* __restrict__ gt, int N,
+                                                             double m0, double m1, double m2, double m3, double s0, double s1, double s2,
+                                                             double s3, double* __restrict__ out) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const double* a = anchors + 4ll * n;
+        const double* g = gt + 4ll * n;
+        const double aw = a[2] - a[0], ah = a[3] - a[1];
+        out[4ll * n + 0] = (((g[0] - a[0]) / aw) - m0) / s0;
+        out[4ll * n + 1] = (((g[1] - a[1]) / ah) - m1) / s1;
+        out[4ll * n + 2] = (((g[2] - a[2]) / aw) - m2) / s2;
+        out[4ll * n + 3] = (((g[3] - a[3]) / ah) - m3) / s3;
+    }
+}
+}  // namespace
+
+extern "C" int rtn_compute_overlap(rtn_handle_t h, const double* boxes, const double* gts, int N, int G, float* out) {
+    if (!h) return RTN_EINVAL;
+    if (!boxes || !gts || !out || N < 1 || G < 1) return rtn_fail(h, RTN_EINVAL, "compute_overlap: bad argument");
+    long long g = ((long long)N * G + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(compute_overlap_kernel, dim3((unsigned)g), dim3(256), 0, h->stream, boxes, gts, N, G, out);
+    RTN_CHECK_LAUNCH(h, "compute_overlap_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_gt_annotations(rtn_handle_t h, const float* overlaps, int N, int G, double negative_overlap, double positive_overlap,
+                                  uint8_t* positive, uint8_t* ignore, int64_t* argmax) {
+    if (!h) return RTN_EINVAL;
+    if (!overlaps || !positive || !ignore || !argmax || N < 1 || G < 1) return rtn_fail(h, RTN_EINVAL, "gt_annotations: bad argument");
+    unsigned g = (unsigned)((N + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(gt_annotations_kernel, dim3(g), dim3(256), 0, h->stream, overlaps, N, G, (float)negative_overlap,
+                       (float)positive_overlap, positive, ignore, (long long*)argmax);
+    RTN_CHECK_LAUNCH(h, "gt_annotations_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_bbox_transform(rtn_handle_t h, const double* anchors, const double* gt_boxes, int N, const double* mean4,
+                                  const double* std4, double* out) {
+    if (!h) return RTN_EINVAL;
+    if (!anchors || !gt_boxes || !mean4 || !std4 || !out || N < 1) return rtn_fail(h, RTN_EINVAL, "bbox_transform: bad argument");
+    unsigned g = (unsigned)((N + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bbox_transform_kernel, dim3(g), dim3(256), 0, h->stream, anchors, gt_boxes, N, mean4[0], mean4[1], mean4[2], mean4[3],
+                       std4[0], std4[1], std4[2], std4[3], out);
+    RTN_CHECK_LAUNCH(h, "bbox_transform_kernel");
     return RTN_OK;
 }

@@ -103,7 +103,8 @@ __device__ __forceinline__ void bitonic_sort_desc(u64* s, int P, int t, int nthr
 __global__ __launch_bounds__(NMS_T) void nms_kernel(const DevAnchorCfg c, int K, const float* __restrict__ regression,
                                                     const u64* __restrict__ keys_all, const int* __restrict__ counts, float cw,
                                                     float ch, float iou_thr, int max_det, u64* __restrict__ sel_keys,
-                                                    float4* __restrict__ sel_boxes, int* __restrict__ sel_count) {
+                                                    float4* __restrict__ sel_boxes, int* __restrict__ sel_count,
+                                                    const float4* __restrict__ boxes_explicit, int n_explicit) {
     __shared__ u64 s_keys[CAP];
     __shared__ float4 s_box[CAP];
     __shared__ unsigned char s_removed[CAP];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(const DevAnchorCfg c, int K,
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int bk = blockIdx.x;
     const int b = bk / K;
-    const int N = c.total;
+    const int N = boxes_explicit ? n_explicit : c.total;
     const long long img_base = (long long)b * N;
     const u64* keys = keys_all + (long long)bk * N;
     int count = counts[bk];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(const DevAnchorCfg c, int K,
         // ---- decode boxes; drop candidates overlapping boxes kept by earlier batches
         for (int i = t; i < nb; i += NMS_T) {
             const int idx = (int)(0xFFFFFFFFu - (unsigned)(s_keys[i] & 0xFFFFFFFFull));
-            const float4 bx = decode_box(c, regression, img_base, idx, cw, ch);
+            const float4 bx = boxes_explicit ? boxes_explicit[img_base + idx] : decode_box(c, regression, img_base, idx, cw, ch);
             s_box[i] = bx;
             unsigned char rem = 0;
             for (int j = 0; j < kept_now; ++j)
@@ -323,22 +324,10 @@ extern "C" size_t rtn_detect_workspace_bytes(int B, int64_t N, int num_classes) 
     return ws_layout(B, N, num_classes).total;
 }
 
-extern "C" int rtn_decode_filter_nms(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, int num_classes, const float* regression,
-                                     const float* classification, int canvas_h, int canvas_w, float score_threshold,
-                                     float nms_threshold, int max_detections, float* boxes, float* scores, int32_t* labels,
-                                     void* workspace, size_t workspace_bytes) {
-    if (!h) return RTN_EINVAL;
-    if (B < 1 || num_classes < 1 || (long long)B * num_classes > 65535) return rtn_fail(h, RTN_EINVAL, "detect: B %d classes %d", B, num_classes);
-    if (max_detections < 1 || max_detections > RTN_MAX_DET) return rtn_fail(h, RTN_EINVAL, "detect: max_detections %d not in [1,%d]", max_detections, RTN_MAX_DET);
-    if ((long long)num_classes * max_detections > MCAP) return rtn_fail(h, RTN_EINVAL, "detect: classes*max_detections > %d", MCAP);
-    if (!(score_threshold >= 0.f)) return rtn_fail(h, RTN_EINVAL, "detect: score_threshold must be >= 0");
-    if (!regression || !classification || !boxes || !scores || !labels || !workspace) return rtn_fail(h, RTN_EINVAL, "detect: null pointer");
-    if (((uintptr_t)regression & 15) || ((uintptr_t)boxes & 15) || ((uintptr_t)workspace & 255))
-        return rtn_fail(h, RTN_EINVAL, "detect: regression/boxes must be 16-byte and workspace 256-byte aligned");
-    DevAnchorCfg d;
-    const int rc = make_dev_cfg(h, cfg, &d);
-    if (rc) return rc;
-    const int N = d.total;
+static int detect_launch(rtn_handle_t h, const DevAnchorCfg& d, int N, int B, int num_classes, const float* regression,
+                         const float4* boxes_explicit, const float* classification, int canvas_h, int canvas_w, float score_threshold,
+                         float nms_threshold, int max_detections, float* boxes, float* scores, int32_t* labels, void* workspace,
+                         size_t workspace_bytes) {
     const WsLayout w = ws_layout(B, N, num_classes);
     if (workspace_bytes < w.total) return rtn_fail(h, RTN_ENOMEM, "detect: workspace %zu < %zu", workspace_bytes, w.total);
     char* ws = (char*)workspace;
@@ -354,10 +343,96 @@ extern "C" int rtn_decode_filter_nms(rtn_handle_t h, const rtn_anchor_cfg_t* cfg
     RTN_CHECK_LAUNCH(h, "detect_candidates_kernel");
     hipLaunchKernelGGL(nms_kernel, dim3(BK), dim3(NMS_T), 0, h->stream, d, num_classes, regression, (const u64*)keys,
                        (const int*)counts, (float)canvas_w, (float)canvas_h, nms_threshold, max_detections, sel_keys, sel_boxes,
-                       sel_count);
+                       sel_count, boxes_explicit, N);
     RTN_CHECK_LAUNCH(h, "nms_kernel");
     hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(NMS_T), 0, h->stream, num_classes, max_detections, (const u64*)sel_keys,
                        (const float4*)sel_boxes, (const int*)sel_count, boxes, scores, labels);
     RTN_CHECK_LAUNCH(h, "merge_topk_kernel");
+    return RTN_OK;
+}
+
+static int detect_check(rtn_handle_t h, int B, int num_classes, float score_threshold, int max_detections, const void* a, const void* b,
+                        const void* boxes, const void* scores, const void* labels, const void* workspace) {
+    if (B < 1 || num_classes < 1 || (long long)B * num_classes > 65535) return rtn_fail(h, RTN_EINVAL, "detect: B %d classes %d", B, num_classes);
+    if (max_detections < 1 || max_detections > RTN_MAX_DET) return rtn_fail(h, RTN_EINVAL, "detect: max_detections %d not in [1,%d]", max_detections, RTN_MAX_DET);
+    if ((long long)num_classes * max_detections > MCAP) return rtn_fail(h, RTN_EINVAL, "detect: classes*max_detections > %d", MCAP);
+    if (!(score_threshold >= 0.f)) return rtn_fail(h, RTN_EINVAL, "detect: score_threshold must be >= 0");
+    if (!a || !b || !boxes || !scores || !labels || !workspace) return rtn_fail(h, RTN_EINVAL, "detect: null pointer");
+    if (((uintptr_t)a & 15) || ((uintptr_t)boxes & 15) || ((uintptr_t)workspace & 255))
+        return rtn_fail(h, RTN_EINVAL, "detect: regression/boxes must be 16-byte and workspace 256-byte aligned");
+    return RTN_OK;
+}
+
+extern "C" int rtn_decode_filter_nms(rtn_handle_t h, const rtn_anchor_cfg_t* cfg, int B, int num_classes, const float* regression,
+                                     const float* classification, int canvas_h, int canvas_w, float score_threshold,
+                                     float nms_threshold, int max_detections, float* boxes, float* scores, int32_t* labels,
+                                     void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    int rc = detect_check(h, B, num_classes, score_threshold, max_detections, regression, classification, boxes, scores, labels, workspace);
+    if (rc) return rc;
+    DevAnchorCfg d;
+    rc = make_dev_cfg(h, cfg, &d);
+    if (rc) return rc;
+    return detect_launch(h, d, d.total, B, num_classes, regression, nullptr, classification, canvas_h, canvas_w, score_threshold,
+                         nms_threshold, max_detections, boxes, scores, labels, workspace, workspace_bytes);
+}
+
+/* FilterDetections on explicit boxes (model/layers.py:177-264, 267-332) */
+extern "C" int rtn_filter_detections(rtn_handle_t h, int B, int64_t N, int num_classes, const float* in_boxes, const float* classification,
+                                     float score_threshold, float nms_threshold, int max_detections, float* boxes, float* scores,
+                                     int32_t* labels, void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (N < 1 || N > (1 << 30)) return rtn_fail(h, RTN_EINVAL, "filter_detections: N");
+    const int rc = detect_check(h, B, num_classes, score_threshold, max_detections, in_boxes, classification, boxes, scores, labels, workspace);
+    if (rc) return rc;
+    DevAnchorCfg d;
+    memset(&d, 0, sizeof(d));
+    return detect_launch(h, d, (int)N, B, num_classes, nullptr, (const float4*)in_boxes, classification, 0, 0, score_threshold,
+                         nms_threshold, max_detections, boxes, scores, labels, workspace, workspace_bytes);
+}
+
+namespace {
+// RegressBoxes: model/utils.py:84-112 with explicit mean/std, float32 op by op
+__global__ __launch_bounds__(256) void regress_boxes_kernel(const float4* __restrict__ anchors, const float4* __restrict__ deltas, long long n,
+                                                            float m0, float m1, float m2, float m3, float s0, float s1, float s2, float s3,
+                                                            float4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = anchors[i], d = deltas[i];
+        const float w = a.z - a.x, hh = a.w - a.y;
+        out[i] = make_float4(a.x + (d.x * s0 + m0) * w, a.y + (d.y * s1 + m1) * hh, a.z + (d.z * s2 + m2) * w, a.w + (d.w * s3 + m3) * hh);
+    }
+}
+// ClipBoxes: model/layers.py:157-171
+__global__ __launch_bounds__(256) void clip_boxes_kernel(const float4* __restrict__ in, long long n, float width, float height,
+                                                         float4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float4 b = in[i];
+        out[i] = make_float4(fminf(fmaxf(b.x, 0.f), width), fminf(fmaxf(b.y, 0.f), height), fminf(fmaxf(b.z, 0.f), width),
+                             fminf(fmaxf(b.w, 0.f), height));
+    }
+}
+}  // namespace
+
+extern "C" int rtn_regress_boxes(rtn_handle_t h, const float* anchors, const float* deltas, int64_t n_boxes, const float* mean4,
+                                 const float* std4, float* out) {
+    if (!h) return RTN_EINVAL;
+    if (!anchors || !deltas || !mean4 || !std4 || !out || n_boxes < 1) return rtn_fail(h, RTN_EINVAL, "regress_boxes: bad argument");
+    if (((uintptr_t)anchors & 15) || ((uintptr_t)deltas & 15) || ((uintptr_t)out & 15)) return rtn_fail(h, RTN_EINVAL, "regress_boxes: alignment");
+    long long g = (n_boxes + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(regress_boxes_kernel, dim3((unsigned)g), dim3(256), 0, h->stream, (const float4*)anchors, (const float4*)deltas,
+                       (long long)n_boxes, mean4[0], mean4[1], mean4[2], mean4[3], std4[0], std4[1], std4[2], std4[3], (float4*)out);
+    RTN_CHECK_LAUNCH(h, "regress_boxes_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_clip_boxes(rtn_handle_t h, const float* in, int64_t n_boxes, float width, float height, float* out) {
+    if (!h) return RTN_EINVAL;
+    if (!in || !out || n_boxes < 1) return rtn_fail(h, RTN_EINVAL, "clip_boxes: bad argument");
+    if (((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return rtn_fail(h, RTN_EINVAL, "clip_boxes: alignment");
+    long long g = (n_boxes + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(clip_boxes_kernel, dim3((unsigned)g), dim3(256), 0, h->stream, (const float4*)in, (long long)n_boxes, width, height, (float4*)out);
+    RTN_CHECK_LAUNCH(h, "clip_boxes_kernel");
     return RTN_OK;
 }

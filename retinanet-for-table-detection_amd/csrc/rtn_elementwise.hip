@@ -218,3 +218,61 @@ extern "C" int rtn_relu(rtn_handle_t h, const void* in, void* out, int dtype, in
     RTN_CHECK_LAUNCH(h, "relu_kernel");
     return RTN_OK;
 }
+
+namespace {
+// UpsampleLike (model/layers.py:89-98): legacy TF nearest, src = min(floor(dst * in/out), in-1), ratio in float32
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Hs, int Ws,
+                                                               int Hd, int Wd, int cv, float rh, float rw) {
+    const long long total = (long long)B * Hd * Wd * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        long long r = i / cv;
+        const int x = (int)(r % Wd);
+        r /= Wd;
+        const int y = (int)(r % Hd);
+        const int b = (int)(r / Hd);
+        int sy = (int)floorf((float)y * rh), sx = (int)floorf((float)x * rw);
+        sy = sy < Hs - 1 ? sy : Hs - 1;
+        sx = sx < Ws - 1 ? sx : Ws - 1;
+        dst[i] = src[(((long long)b * Hs + sy) * Ws + sx) * cv + c];
+    }
+}
+
+// utils.preprocess_image (model/utils.py:19-47): float32 cast, then mode 0 'tf' x/127.5-1, 1 'caffe' BGR mean subtraction,
+// 2 'custom_tf' x/scale - sub (model/Parameters.py:23-24)
+template <typename SRC>
+__global__ __launch_bounds__(256) void preprocess_kernel(const SRC* __restrict__ src, float* __restrict__ dst, long long n, int mode,
+                                                         float scale, float sub) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = (float)src[i];
+        if (mode == 0) v = __fsub_rn(__fdiv_rn(v, 127.5f), 1.0f);
+        else if (mode == 1) { const int c = (int)(i % 3); v = __fsub_rn(v, c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f)); }
+        else if (mode == 2) v = __fsub_rn(__fdiv_rn(v, scale), sub);
+        dst[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int rtn_upsample_nearest(rtn_handle_t h, const void* src, void* dst, int dtype, int B, int Hs, int Ws, int Hd, int Wd, int C) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || B < 1 || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || C < 1) return rtn_fail(h, RTN_EINVAL, "upsample_nearest: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "upsample_nearest: bad dtype");
+    const int es = rtn_dtype_size(dtype);
+    if ((C * es) % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return rtn_fail(h, RTN_EINVAL, "upsample_nearest: alignment");
+    const int cv = C * es / 16;
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for((long long)B * Hd * Wd * cv)), dim3(256), 0, h->stream, (const uint4*)src,
+                       (uint4*)dst, B, Hs, Ws, Hd, Wd, cv, (float)Hs / (float)Hd, (float)Ws / (float)Wd);
+    RTN_CHECK_LAUNCH(h, "upsample_nearest_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_preprocess_image(rtn_handle_t h, const void* src, int src_dtype, float* dst, int64_t n, int mode, float scale, float sub) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || n < 1 || mode < 0 || mode > 2) return rtn_fail(h, RTN_EINVAL, "preprocess_image: bad argument");
+    if (src_dtype != RTN_F32 && src_dtype != 2) return rtn_fail(h, RTN_EINVAL, "preprocess_image: src dtype must be f32 or u8");
+    if (mode == 1 && n % 3) return rtn_fail(h, RTN_EINVAL, "preprocess_image: caffe mode needs 3 interleaved channels");
+    if (src_dtype == 2) hipLaunchKernelGGL((preprocess_kernel<unsigned char>), dim3(grid_for(n)), dim3(256), 0, h->stream, (const unsigned char*)src, dst, (long long)n, mode, scale, sub);
+    else                hipLaunchKernelGGL((preprocess_kernel<float>), dim3(grid_for(n)), dim3(256), 0, h->stream, (const float*)src, dst, (long long)n, mode, scale, sub);
+    RTN_CHECK_LAUNCH(h, "preprocess_kernel");
+    return RTN_OK;
+}

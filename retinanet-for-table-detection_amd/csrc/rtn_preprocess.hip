@@ -1,0 +1,316 @@
+// rtn_preprocess.hip — page preprocessing on the device:
+//   DetectTablesUtils.py:251-261  cvtColor(BGR2GRAY) -> adaptiveThreshold(255, GAUSSIAN_C, BINARY, 11, 2) ->
+//                                 distanceTransform(L2 mask 5 | L1 | C) -> merge(b,g,r) -> imwrite (saturate to uint8)
+//   model/utils.py:43-46,140-154  x/127.5 - 1, then cv2.resize(fx=fy=scale, INTER_CUBIC), written into the zero-padded batch
+//                                 canvas of Generator.compute_inputs (csv_generator.py:320-336).
+// OpenCV's algorithms are restated (opencv is neither vendored nor pinned by the reference; oracle/ref_preprocess.py is the
+// CPU statement of the same and is checked against the reference's sample page pair).
+//
+// Distance transform = OpenCV's two-pass chamfer in 16.16 fixed point, kept EXACT and made parallel: within one raster row the
+// recurrence D[x] = min(t[x], D[x-1] + a) is a prefix minimum of t[x] - a*x, so a 1024-thread workgroup sweeps the rows of one
+// (page, metric) in order — previous rows live in an LDS ring — and scans each row in parallel.  24 workgroups serve a batch
+// of 8 pages x 3 metrics concurrently.  FP contraction is off: the Gaussian mean and the bicubic taps round like the oracle.
+#include "rtn_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int DT_T = 1024;
+constexpr int DT_MAXW = 4096;
+constexpr int DT_E = DT_MAXW / DT_T;          // columns per thread
+constexpr int DT_INF = (0x7fffffff >> 2);
+constexpr int DT_SHIFT = 16;
+
+__constant__ float c_gauss11[11];
+
+// pass A: gray (fixed point, OpenCV BGR2GRAY) + horizontal 11-tap Gaussian, replicate border
+__global__ __launch_bounds__(256) void gray_hblur_kernel(const unsigned char* __restrict__ src, int channels, int B, int H, int W,
+                                                         unsigned char* __restrict__ gray, float* __restrict__ tmp) {
+    const long long total = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long long row = i / W;                      // b*H + y
+        float acc = 0.f;
+        unsigned char centre = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            int xx = x + k - 5;
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            const unsigned char* p = src + (row * W + xx) * channels;
+            const int g = channels == 3 ? ((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14) : p[0];
+            if (k == 5) centre = (unsigned char)g;
+            acc = acc + (float)g * c_gauss11[k];
+        }
+        gray[i] = centre;
+        tmp[i] = acc;
+    }
+}
+
+// pass B: vertical Gaussian, round half to even, threshold: 255 if gray - mean > -2 else 0
+__global__ __launch_bounds__(256) void vblur_threshold_kernel(const unsigned char* __restrict__ gray, const float* __restrict__ tmp, int B,
+                                                              int H, int W, int delta, unsigned char* __restrict__ binary) {
+    const long long total = (long long)B * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long long r = i / W;
+        const int y = (int)(r % H);
+        const long long b = r / H;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            int yy = y + k - 5;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            acc = acc + tmp[(b * H + yy) * W + x] * c_gauss11[k];
+        }
+        float m = rintf(acc);
+        m = m < 0.f ? 0.f : (m > 255.f ? 255.f : m);
+        binary[i] = ((int)gray[i] - (int)m > -delta) ? 255 : 0;
+    }
+}
+
+__device__ __forceinline__ int wave_scan_min(int v, int lane) {      // inclusive prefix min over the 64 lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(v, o, 64);
+        if (lane >= o) v = v < n ? v : n;
+    }
+    return v;
+}
+
+// One workgroup = one (page, metric).  dir = +1 forward raster pass, -1 backward pass (mirror image of the same code).
+// ring[3][W]: rows y-2, y-1 (forward) or y+2, y+1 (backward) and the row being written.
+template <bool BACKWARD>
+__device__ void dt_pass(const unsigned char* __restrict__ bin, int* __restrict__ D, int H, int W, int a, int b, int c,
+                        int* ring, int* wagg, unsigned char* __restrict__ out, int ch) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int x0 = t * DT_E;
+    // ring rows start as "infinity"
+    for (int i = t; i < 3 * DT_MAXW; i += DT_T) ring[i] = DT_INF;
+    __syncthreads();
+    for (int step = 0; step < H; ++step) {
+        const int y = BACKWARD ? H - 1 - step : step;
+        const int* p1 = ring + ((step + 2) % 3) * DT_MAXW;      // previous row in sweep order
+        const int* p2 = ring + ((step + 1) % 3) * DT_MAXW;      // the one before
+        int* cur = ring + (step % 3) * DT_MAXW;
+        int v[DT_E];
+        // ---- candidates from the two previous rows (+ the forward value of this pixel in the backward pass)
+#pragma unroll
+        for (int e = 0; e < DT_E; ++e) {
+            const int x = x0 + e;
+            int tv = DT_INF;
+            if (x < W) {
+                auto at = [&](const int* r, int xx) { return (xx >= 0 && xx < W) ? r[xx] : DT_INF; };
+                tv = min(min(at(p1, x - 1) + b, p1[x] + a), at(p1, x + 1) + b);
+                if (c > 0) {
+                    tv = min(tv, min(at(p2, x - 1), at(p2, x + 1)) + c);
+                    tv = min(tv, min(at(p1, x - 2), at(p1, x + 2)) + c);
+                }
+                if (BACKWARD) tv = min(tv, D[(long long)y * W + x]);
+                else if (bin[(long long)y * W + x] == 0) tv = 0;
+                tv = min(tv, DT_INF);
+            }
+            // min-plus scan along the sweep direction: forward uses t - a*x, backward t + a*x scanned from the right
+            v[e] = BACKWARD ? tv + a * x : tv - a * x;
+        }
+        // ---- in-thread scan, then workgroup scan of the thread aggregates
+        if (!BACKWARD) {
+#pragma unroll
+            for (int e = 1; e < DT_E; ++e) v[e] = min(v[e], v[e - 1]);
+        } else {
+#pragma unroll
+            for (int e = DT_E - 2; e >= 0; --e) v[e] = min(v[e], v[e + 1]);
+        }
+        // thread order along the sweep: forward t ascending, backward t descending -> scan over rt
+        const int agg = BACKWARD ? v[0] : v[DT_E - 1];
+        // mirror lanes for the backward pass so that one inclusive scan routine serves both
+        int s_in = agg;
+        if (BACKWARD) s_in = __shfl(agg, 63 - lane, 64);
+        int incl = wave_scan_min(s_in, lane);
+        const int wtot = __shfl(incl, 63, 64);
+        int excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0x7fffffff;
+        if (lane == 0) wagg[BACKWARD ? (DT_T / 64 - 1 - wave) : wave] = wtot;
+        __syncthreads();
+        // prefix over waves (16 values): every thread folds the waves before its own
+        int carry = 0x7fffffff;
+        const int wpos = BACKWARD ? (DT_T / 64 - 1 - wave) : wave;
+        for (int w = 0; w < wpos; ++w) carry = min(carry, wagg[w]);
+        excl = min(excl, carry);
+        if (BACKWARD) excl = __shfl(excl, 63 - lane, 64);          // un-mirror: lane L gets the prefix of everything to its right
+#pragma unroll
+        for (int e = 0; e < DT_E; ++e) {
+            const int x = x0 + e;
+            if (x < W) {
+                const int s = min(v[e], excl);
+                const int d = BACKWARD ? s - a * x : s + a * x;
+                cur[x] = d;
+                if (BACKWARD) {
+                    // distanceTransform result (float), then imwrite's saturate_cast<uchar>
+                    float f = rintf((float)d * (1.0f / (float)(1 << DT_SHIFT)));
+                    f = f > 255.f ? 255.f : f;
+                    out[((long long)y * W + x) * 3 + ch] = (unsigned char)f;
+                } else {
+                    D[(long long)y * W + x] = d;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid = B * 3 ; metric 0: DIST_L2 mask 5 -> channel 0 (b), 1: DIST_L1 -> channel 1 (g), 2: DIST_C -> channel 2 (r)
+__global__ __launch_bounds__(DT_T) void dt3_kernel(const unsigned char* __restrict__ binary, int* __restrict__ scratch, int H, int W,
+                                                   unsigned char* __restrict__ out) {
+    __shared__ int ring[3 * DT_MAXW];
+    __shared__ int wagg[DT_T / 64];
+    const int img = blockIdx.x / 3, metric = blockIdx.x % 3;
+    const int one = 1 << DT_SHIFT;
+    const int a = one;
+    const int b = metric == 0 ? 91750 /* round(1.4 * 65536) */ : (metric == 1 ? 2 * one : one);
+    const int c = metric == 0 ? 143976 /* round(2.1969 * 65536) */ : 0;
+    const unsigned char* bin = binary + (long long)img * H * W;
+    int* D = scratch + ((long long)img * 3 + metric) * H * W;
+    unsigned char* o = out + (long long)img * H * W * 3;
+    dt_pass<false>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
+    __syncthreads();
+    dt_pass<true>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
+}
+
+// cv2.resize(INTER_CUBIC): A = -0.75, src = (dst + 0.5)/scale - 0.5, replicate border; optional fused x/127.5 - 1 for uint8 input
+__device__ __forceinline__ void cubic_coeffs(float x, float (&k)[4]) {
+    const float A = -0.75f;
+    k[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+    k[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    k[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+    k[3] = 1.f - k[0] - k[1] - k[2];
+}
+
+template <int SRC_U8, int DST_BF16>
+__global__ __launch_bounds__(256) void resize_cubic_kernel(const void* __restrict__ src, int H, int W, int C, double inv_scale,
+                                                           void* __restrict__ dst, int Ho, int Wo, long long dst_row_stride) {
+    const long long total = (long long)Ho * Wo * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C);
+        const long long r = i / C;
+        const int dx = (int)(r % Wo), dy = (int)(r / Wo);
+        const double fx = ((double)dx + 0.5) * inv_scale - 0.5, fy = ((double)dy + 0.5) * inv_scale - 0.5;
+        const int sx = (int)floor(fx), sy = (int)floor(fy);
+        float kx[4], ky[4];
+        cubic_coeffs((float)(fx - (double)sx), kx);
+        cubic_coeffs((float)(fy - (double)sy), ky);
+        float rows[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int yy = sy - 1 + j;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int xx = sx - 1 + k;
+                xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                const long long si = ((long long)yy * W + xx) * C + ch;
+                float v;
+                if (SRC_U8) v = __fsub_rn(__fdiv_rn((float)((const unsigned char*)src)[si], 127.5f), 1.0f);
+                else v = ((const float*)src)[si];
+                acc = acc + v * kx[k];
+            }
+            rows[j] = acc;
+        }
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o = o + rows[j] * ky[j];
+        const long long di = (long long)dy * dst_row_stride + (long long)dx * C + ch;
+        if (DST_BF16) {
+            const __bf16 hb = (__bf16)o;
+            ((unsigned short*)dst)[di] = __builtin_bit_cast(unsigned short, hb);
+        } else {
+            ((float*)dst)[di] = o;
+        }
+    }
+}
+
+inline unsigned grid_for(long long work, int cap = 4096) {
+    long long g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+bool g_gauss_uploaded[64] = {false};
+
+}  // namespace
+
+extern "C" size_t rtn_preprocess_dt3_workspace_bytes(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return 0;
+    const size_t px = (size_t)B * H * W;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return al(px) /* gray */ + al(px * 4) /* row-blurred f32 */ + al(px) /* binary */ + al(px * 3 * 4) /* forward distances */;
+}
+
+extern "C" int rtn_preprocess_dt3(rtn_handle_t h, const uint8_t* src, int channels, int B, int H, int W, uint8_t* dst,
+                                  uint8_t* binary_out, void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || !workspace || B < 1 || H < 1 || W < 1 || (channels != 1 && channels != 3)) return rtn_fail(h, RTN_EINVAL, "preprocess_dt3: bad argument");
+    if (W > DT_MAXW) return rtn_fail(h, RTN_EINVAL, "preprocess_dt3: pages wider than %d px are not supported (got %d)", DT_MAXW, W);
+    if ((long long)B * 3 > 65535) return rtn_fail(h, RTN_EINVAL, "preprocess_dt3: batch too large");
+    if (workspace_bytes < rtn_preprocess_dt3_workspace_bytes(B, H, W)) return rtn_fail(h, RTN_ENOMEM, "preprocess_dt3: workspace %zu < %zu", workspace_bytes, rtn_preprocess_dt3_workspace_bytes(B, H, W));
+    if ((uintptr_t)workspace & 255) return rtn_fail(h, RTN_EINVAL, "preprocess_dt3: workspace must be 256-byte aligned");
+    if (h->device >= 0 && h->device < 64 && !g_gauss_uploaded[h->device]) {
+        // getGaussianKernel(11, sigma <= 0): sigma = 0.3*((n-1)*0.5 - 1) + 0.8 = 2.0, double math, stored as float
+        double k[11], sum = 0.0;
+        const double sigma = ((11 - 1) * 0.5 - 1) * 0.3 + 0.8;
+        for (int i = 0; i < 11; ++i) { const double x = i - 5.0; k[i] = exp(-0.5 / (sigma * sigma) * x * x); sum += k[i]; }
+        float kf[11];
+        for (int i = 0; i < 11; ++i) kf[i] = (float)(k[i] / sum);
+        RTN_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_gauss11), kf, sizeof(kf)));
+        g_gauss_uploaded[h->device] = true;
+    }
+    const size_t px = (size_t)B * H * W;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* ws = (char*)workspace;
+    unsigned char* gray = (unsigned char*)ws;
+    float* tmp = (float*)(ws + al(px));
+    unsigned char* binary = (unsigned char*)(ws + al(px) + al(px * 4));
+    int* scratch = (int*)(ws + al(px) + al(px * 4) + al(px));
+    hipLaunchKernelGGL(gray_hblur_kernel, dim3(grid_for((long long)px)), dim3(256), 0, h->stream, src, channels, B, H, W, gray, tmp);
+    RTN_CHECK_LAUNCH(h, "gray_hblur_kernel");
+    hipLaunchKernelGGL(vblur_threshold_kernel, dim3(grid_for((long long)px)), dim3(256), 0, h->stream, (const unsigned char*)gray, (const float*)tmp, B, H, W, 2, binary);
+    RTN_CHECK_LAUNCH(h, "vblur_threshold_kernel");
+    if (binary_out) RTN_HIP(h, hipMemcpyAsync(binary_out, binary, px, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(dt3_kernel, dim3(B * 3), dim3(DT_T), 0, h->stream, (const unsigned char*)binary, scratch, H, W, dst);
+    RTN_CHECK_LAUNCH(h, "dt3_kernel");
+    return RTN_OK;
+}
+
+/* distance transforms of a caller-provided binary image (the distanceTransform x3 + merge + saturate part alone) */
+extern "C" int rtn_distance_transform3(rtn_handle_t h, const uint8_t* binary, int B, int H, int W, uint8_t* dst, void* workspace,
+                                       size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (!binary || !dst || !workspace || B < 1 || H < 1 || W < 1) return rtn_fail(h, RTN_EINVAL, "distance_transform3: bad argument");
+    if (W > DT_MAXW || (long long)B * 3 > 65535) return rtn_fail(h, RTN_EINVAL, "distance_transform3: width %d / batch %d unsupported", W, B);
+    if (workspace_bytes < (size_t)B * H * W * 12) return rtn_fail(h, RTN_ENOMEM, "distance_transform3: workspace too small");
+    hipLaunchKernelGGL(dt3_kernel, dim3(B * 3), dim3(DT_T), 0, h->stream, binary, (int*)workspace, H, W, dst);
+    RTN_CHECK_LAUNCH(h, "dt3_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, int H, int W, int C, double scale, void* dst, int dst_dtype,
+                                int Ho, int Wo, int64_t dst_row_stride) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || H < 1 || W < 1 || C < 1 || !(scale > 0.0)) return rtn_fail(h, RTN_EINVAL, "resize_cubic: bad argument");
+    if (src_dtype != RTN_F32 && src_dtype != 2) return rtn_fail(h, RTN_EINVAL, "resize_cubic: src must be f32 or u8");
+    if (dst_dtype != RTN_F32 && dst_dtype != RTN_BF16) return rtn_fail(h, RTN_EINVAL, "resize_cubic: dst must be f32 or bf16");
+    // cv2.resize: dsize = saturate_cast<int>(ssize * scale) (round half to even)
+    if (Ho != (int)nearbyint(H * scale) || Wo != (int)nearbyint(W * scale)) return rtn_fail(h, RTN_EINVAL, "resize_cubic: output %dx%d is not round(%dx%d * %.6f)", Ho, Wo, H, W, scale);
+    if (dst_row_stride < (int64_t)Wo * C) return rtn_fail(h, RTN_EINVAL, "resize_cubic: dst_row_stride too small");
+    const long long total = (long long)Ho * Wo * C;
+    const double inv = 1.0 / scale;
+    dim3 g(grid_for(total, 8192)), b(256);
+#define RS(S, D) hipLaunchKernelGGL((resize_cubic_kernel<S, D>), g, b, 0, h->stream, src, H, W, C, inv, dst, Ho, Wo, (long long)dst_row_stride)
+    if (src_dtype == 2) { if (dst_dtype == RTN_BF16) RS(1, 1); else RS(1, 0); }
+    else                { if (dst_dtype == RTN_BF16) RS(0, 1); else RS(0, 0); }
+#undef RS
+    RTN_CHECK_LAUNCH(h, "resize_cubic_kernel");
+    return RTN_OK;
+}
