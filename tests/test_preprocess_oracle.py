@@ -47,7 +47,14 @@ def test_resize_cubic_properties():
     assert P.resize_cubic(img, 0.4672897196261682).shape == (19, 14, 3)
     const = np.full((12, 9, 3), 0.25, np.float32)
     assert np.allclose(P.resize_cubic(const, 1.7), 0.25, atol=1e-6)           # partition of unity
-    ramp = np.tile(np.arange(32, dtype=np.float32)[None, :, None], (8, 1, 1))
-    up = P.resize_cubic(ramp, 2.0)[:, 8:-8, 0]                               # cubic convolution reproduces linear ramps
-    want = (np.arange(64) + 0.5) / 2 - 0.5
-    assert np.allclose(up, want[None, 8:-8], atol=1e-4)
+    # the taps are Keys' cubic convolution kernel with a = -0.75 (OpenCV's INTER_CUBIC), evaluated independently in float64
+    def keys(t, a=-0.75):
+        t = abs(t)
+        return (a + 2) * t ** 3 - (a + 3) * t ** 2 + 1 if t <= 1 else (a * t ** 3 - 5 * a * t ** 2 + 8 * a * t - 4 * a if t < 2 else 0.0)
+    sig = rng.uniform(-1, 1, size=32)
+    up = P.resize_cubic(np.tile(sig.astype(np.float32)[None, :, None], (8, 1, 1)), 2.0)[3, :, 0]
+    for dx in range(8, 56):
+        f = (dx + 0.5) / 2.0 - 0.5
+        s0 = int(np.floor(f))
+        want = sum(keys(f - (s0 - 1 + k)) * np.float32(sig[s0 - 1 + k]) for k in range(4))
+        assert abs(up[dx] - want) < 1e-5
