@@ -144,6 +144,9 @@ int rtn_pack_dgrad_weights(rtn_handle_t h, const void* w_fwd, void* w_dgrad, int
  * once per step; the five pyramid levels and any number of micro-batches add into the same buffer).  */
 size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d);
 int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes);
+/* the same with BiasAddGrad fused: db[0..db_n) += sum over pixels of dY[:, n] (db_n <= N) */
+int rtn_conv2d_wgrad_bias(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace,
+                          size_t workspace_bytes);
 /* db[n] += sum over rows of dy[row][n]   (rows x N matrix with leading dimension ld, dtype bf16/f32) */
 int rtn_bias_grad(rtn_handle_t h, const void* dy, int dtype, int64_t rows, int N, int64_t ld, float* db);
 /* out[r][0..cout) = cast(in[r][0..cin)), zero beyond cin */

@@ -15,6 +15,7 @@
 // their 128-byte halves, which makes the transposed reads of a 32-lane half conflict-free.  The pixel range is split
 // over gridDim.y; partial tiles are added into the f32 gradient with global_atomic_add_f32.
 #include "rtn_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -47,6 +48,8 @@ struct WGroup {
 struct WParams {
     WGroup g[RTN_MAX_GROUPS];
     float* dW;
+    float* db;           // optional bias gradient (BiasAddGrad fused: column sums of dY), accumulated by the tile_k == 0 blocks
+    int db_n;            // valid bias entries
     const uint4* rowinfo;
     int ngroups, total_tiles, tiles_per_split, ntiles_k;
     int N, Ktot;
@@ -118,7 +121,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
 #pragma unroll
         for (int j = 0; j < FI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool do_bias = p.db != nullptr && tile_k == 0;
+    float bsum[CE];
+#pragma unroll
+    for (int j = 0; j < CE; ++j) bsum[j] = 0.f;
     uint4 ra[4], rb[4];
+    uint4 ri[4];                                  // row info of the NEXT tile to load (prefetched one tile ahead)
+#define WG_ROWINFO(TILE)                                                                                            \
+    {                                                                                                               \
+        const int tt_ = (TILE) < thi ? (TILE) : thi - 1;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ri[i_] = p.rowinfo[(long long)tt_ * 64 + r0 + 16 * i_];    \
+    }
 #define WG_LOAD(TILE)                                                                                               \
     {                                                                                                               \
         int gi_ = 0;                                                                                                \
@@ -131,17 +144,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
             (void*)G_.dy, 0, (int)__builtin_amdgcn_readfirstlane((int)G_.dy_bytes), 0x00020000);                    \
         const unsigned delta_ = (unsigned)(kh * G_.x_row_stride_b + kw * p.pix_stride_b + coff * ES);               \
         const int Hin_ = G_.Hin, Win_ = G_.Win;                                                                     \
-        uint4 ri_[4];                                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ri_[i_] = p.rowinfo[(long long)(TILE) * 64 + r0 + 16 * i_]; \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
-            const int iy_ = (int)(short)(ri_[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri_[i_].z >> 16) + kw;       \
+            const int iy_ = (int)(short)(ri[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri[i_].z >> 16) + kw;         \
             const bool ok_ = kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;            \
-            rb[i_] = buffer_load16(xs_, ok_ ? ri_[i_].x + delta_ : OOB_OFFSET);                                     \
-            ra[i_] = buffer_load16(ys_, (nvalid && ri_[i_].y != OOB_OFFSET) ? ri_[i_].y + dyo : OOB_OFFSET);        \
+            rb[i_] = buffer_load16(xs_, ok_ ? ri[i_].x + delta_ : OOB_OFFSET);                                      \
+            ra[i_] = buffer_load16(ys_, (nvalid && ri[i_].y != OOB_OFFSET) ? ri[i_].y + dyo : OOB_OFFSET);          \
         }                                                                                                           \
+        WG_ROWINFO((TILE) + 1);                                                                                     \
     }
 #define WG_STORE(BUF)                                                                                               \
     {                                                                                                               \
+        if (do_bias) {                                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
+                const unsigned w4_[4] = {ra[i_].x, ra[i_].y, ra[i_].z, ra[i_].w};                                   \
+                if constexpr (ES == 2) {                                                                            \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                              \
+                        bsum[2 * j_] += __uint_as_float(w4_[j_] << 16);                                             \
+                        bsum[2 * j_ + 1] += __uint_as_float(w4_[j_] & 0xffff0000u);                                 \
+                    }                                                                                               \
+                } else {                                                                                            \
+                    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) bsum[j_] += __uint_as_float(w4_[j_]);          \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
         char* A_ = lds + (BUF) * 2 * WG_TILE_B;                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
             *reinterpret_cast<uint4*>(A_ + st_off + i_ * 16 * WG_ROWB) = ra[i_];                                    \
@@ -149,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
         }                                                                                                           \
     }
 
+    WG_ROWINFO(tlo);
     WG_LOAD(tlo);
     WG_STORE(0);
     __syncthreads();
@@ -211,8 +237,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
         cur ^= 1;
     }
 #undef WG_LOAD
+#undef WG_ROWINFO
 #undef WG_STORE
 
+    if (do_bias) {       // threads t = ch + 16*r0 share chunk column ch: sum their partials through LDS, one atomic per channel
+        float* sb = reinterpret_cast<float*>(lds);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CE; ++j) sb[t * CE + j] = bsum[j];
+        __syncthreads();
+        if (t < 16) {
+#pragma unroll
+            for (int j = 0; j < CE; ++j) {
+                float v = 0.f;
+                for (int rr = 0; rr < 16; ++rr) v += sb[(t + 16 * rr) * CE + j];
+                const int n = n0 + t * CE + j;
+                if (n < p.db_n) unsafeAtomicAdd(p.db + n, v);
+            }
+        }
+    }
     // D[row = n][col = k]: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
     const int lr = (lane >> 4) * 4, lc = lane & 15;
 #pragma unroll
@@ -243,18 +286,27 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const char* __restrict__
 #pragma unroll
     for (int j = 0; j < CE; ++j) s[j] = 0.f;
     if (r < RP) {
-        for (long long row = (long long)blockIdx.x * RP + r; row < rows; row += (long long)gridDim.x * RP) {
-            const uint4 q = *reinterpret_cast<const uint4*>(dy + row * ld_b + (long long)c * 16);
-            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
-            if constexpr (ES == 2) {
+        const long long step = (long long)gridDim.x * RP;
+        for (long long row = (long long)blockIdx.x * RP + r; row < rows; row += 8 * step) {
+            uint4 q[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[2 * j] += __uint_as_float(w4[j] << 16);
-                    s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+            for (int u = 0; u < 8; ++u) {                 // 8 independent row loads in flight (rows past the end: zeros)
+                const long long rr = row + u * step;
+                q[u] = rr < rows ? *reinterpret_cast<const uint4*>(dy + rr * ld_b + (long long)c * 16) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned w4[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[2 * j] += __uint_as_float(w4[j] << 16);
+                        s[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += __uint_as_float(w4[j]);
             }
         }
     }
@@ -672,7 +724,20 @@ extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
     return (size_t)tiles * 64 * sizeof(uint4);
 }
 
+static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);
+
 extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes) {
+    return wgrad_launch(h, d, dW, nullptr, 0, workspace, workspace_bytes);
+}
+
+/* wgrad with the bias gradient fused: db[0..db_n) += column sums of dY (BiasAddGrad) */
+extern "C" int rtn_conv2d_wgrad_bias(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace,
+                                     size_t workspace_bytes) {
+    if (h && (!db || db_n < 1 || (d && db_n > d->N))) return rtn_fail(h, RTN_EINVAL, "wgrad_bias: bad db / db_n");
+    return wgrad_launch(h, d, dW, db, db_n, workspace, workspace_bytes);
+}
+
+static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes) {
     if (!h) return RTN_EINVAL;
     if (!d || !dW || !workspace) return rtn_fail(h, RTN_EINVAL, "wgrad: null argument");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "wgrad: bad dtype");
@@ -720,6 +785,8 @@ extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float*
     if (tiles > (1 << 24)) return rtn_fail(h, RTN_EINVAL, "wgrad: too many pixels");
     const int CH = es == 2 ? 128 : 64;
     p.dW = dW;
+    p.db = db;
+    p.db_n = db_n;
     p.rowinfo = (const uint4*)workspace;
     p.ngroups = d->ngroups;
     p.total_tiles = (int)tiles;
@@ -735,7 +802,10 @@ extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float*
     const int ntn = (d->N + CH - 1) / CH;
     p.ntiles_k = (int)((Ktot + CH - 1) / CH);
     const long long out_tiles = (long long)ntn * p.ntiles_k;
-    long long nsplit = (1024 + out_tiles - 1) / out_tiles;
+    // target workgroup count (RTN_WGRAD_BLOCKS overrides): measured on the head layers 512 -> 0.57 ms, 1024 -> 0.39 ms
+    long long target = 1024;
+    if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
+    long long nsplit = (target + out_tiles - 1) / out_tiles;
     if (nsplit > tiles) nsplit = tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;

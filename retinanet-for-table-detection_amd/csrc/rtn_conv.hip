@@ -92,6 +92,8 @@ struct KParams {
     int cshift, crun_mask, kw_inv, KW;
     int pix_stride_b, sy, sx, pad_t, pad_l;
     int out_ld, flags, vec_ok;
+    int dense_out;   // out/res/mask are plain [M][ld] matrices: the epilogue needs no (image, pixel) split
+    int dense_in;    // 1x1, stride 1, no padding on a contiguous NHWC input: row m starts at m * pix_stride
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -130,10 +132,14 @@ struct RowRef {
     bool valid;
 };
 
-__device__ __forceinline__ RowRef row_ref(const KGroup& G, int m, int M, int cells, int Wout) {
+__device__ __forceinline__ RowRef row_ref(const KParams& p, const KGroup& G, int m, int M, int cells, int Wout) {
     RowRef r;
     r.valid = m < M;
     const int mc = r.valid ? m : M - 1;            // clamped: address math and loads stay unconditional
+    if (p.dense_out) {                             // image stride == cells * ld everywhere: index by m alone, no division
+        r.b = 0; r.cell = mc; r.opix = mc;
+        return r;
+    }
     r.b = mc / cells;
     r.cell = mc - r.b * cells;
     if (G.out_step > 1) {
@@ -332,7 +338,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + r0 + 32 * i;
-        if (m < M) {
+        if (m < M && p.dense_in) {
+            iy0[i] = 0;
+            ix0[i] = 0;
+            rowbase[i] = (unsigned)((long long)m * p.pix_stride_b);
+        } else if (m < M) {
             const int b = m / cells;
             const int rem = m - b * cells;
             const int oy = rem / Wout;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
     ResVec<ES> pre[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        rows[it] = row_ref(G, m0 + t / TPR + it * RPP, M, cells, Wout);
+        rows[it] = row_ref(p, G, m0 + t / TPR + it * RPP, M, cells, Wout);
         if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, n, pre[it]);
         if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, rows[it], n, pre[it]);
     }
@@ -524,7 +534,11 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + (i * 8 + wave) * 8 + lr;
-        if (m < M) {
+        if (m < M && p.dense_in) {
+            iy0[i] = 0;
+            ix0[i] = 0;
+            rowbase[i] = (unsigned)((long long)m * p.pix_stride_b);
+        } else if (m < M) {
             const int b = m / cells;
             const int rem = m - b * cells;
             const int oy = rem / Wout;
@@ -652,7 +666,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
         ResVec<ES> pre[NITW];
 #pragma unroll
         for (int it = 0; it < NITW; ++it) {
-            rows[it] = row_ref(G, m0 + wm * 64 + hh * 32 + lane / TPRW + it * RPPW, M, cells, Wout);
+            rows[it] = row_ref(p, G, m0 + wm * 64 + hh * 32 + lane / TPRW + it * RPPW, M, cells, Wout);
             rows[it].valid = rows[it].valid && ncol_ok;
             if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, ncol_ok ? n : 0, pre[it]);
             if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, rows[it], ncol_ok ? n : 0, pre[it]);
@@ -827,6 +841,20 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     p.out_ld = d->out_ld;
     p.flags = d->flags;
     p.vec_ok = vec_ok ? 1 : 0;
+    {
+        bool dense_out = !(d->flags & RTN_CONV_RES_UPSAMPLE), dense_in = (d->KH == 1 && d->KW == 1 && d->sy == 1 && d->sx == 1 && d->pad_t == 0 && d->pad_l == 0);
+        for (int i = 0; i < d->ngroups; ++i) {
+            const rtn_conv_group_t& s = d->g[i];
+            const long long cells = (long long)s.Hout * s.Wout;
+            if (s.out_step > 1 || s.out_off != 0 || s.out_img_stride != cells * d->out_ld) dense_out = false;
+            if (has_res && (s.res_img_stride != cells * s.res_ld)) dense_out = false;
+            if ((d->flags & RTN_CONV_RELU_MASK) && (s.mask_img_stride != cells * s.mask_ld)) dense_out = false;
+            if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
+                s.in_img_stride != (long long)s.Hin * s.in_row_stride) dense_in = false;
+        }
+        p.dense_out = dense_out ? 1 : 0;
+        p.dense_in = dense_in ? 1 : 0;
+    }
     const long long grid = mtiles * p.ntiles_n;
     if (grid < 1 || grid > 0x7fffffffll) return rtn_fail(h, RTN_EINVAL, "conv: grid %lld", grid);
 

@@ -214,13 +214,7 @@ class Trainer:
                         g.out_img_stride, g.out_off = cells * crun, 0
                 wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(dw))
                 max_ws = max(max_ws, wsb)
-                bops.append(("wgrad", dw, dW, name))
-                if lo["has_bias"]:
-                    if head_out:
-                        bops.append(("bgrad", dys[0], B * cells_total, lo["cout"], crun, db))
-                    else:
-                        for gi in range(ng):
-                            bops.append(("bgrad", dys[gi], B * d_f.g[gi].Hout * d_f.g[gi].Wout, lo["cout"], crun, db))
+                bops.append(("wgrad", dw, dW, name, db if lo["has_bias"] else None, lo["cout"]))     # bias gradient fused
                 # ---------- residual inputs of the forward epilogue
                 for gi in range(ng):
                     r = me["res"][gi]
@@ -354,7 +348,10 @@ class Trainer:
         for b in bp["bops"]:
             kind = b[0]
             if kind == "wgrad":
-                h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
+                if b[4] is not None:
+                    h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], bp["ws"].data_ptr(), bp["ws"].numel()))
+                else:
+                    h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
                     self.bucketer.layer_done(b[3])
             elif kind == "dgrad":

@@ -153,7 +153,8 @@ def test_dgrad_and_wgrad(pkg, handle, dtype, case):
     wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d2))
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     dW = torch.full((rows, k * k * cin), 0.5, dtype=torch.float32, device=DEV)
-    handle.check(L.lib.rtn_conv2d_wgrad(handle.raw, C.byref(d2), dW.data_ptr(), ws.data_ptr(), wsb))
+    dbf = torch.full((rows,), 0.25, dtype=torch.float32, device=DEV)
+    handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d2), dW.data_ptr(), dbf.data_ptr(), cout, ws.data_ptr(), wsb))
     db = torch.full((rows,), 0.25, dtype=torch.float32, device=DEV)
     handle.check(L.lib.rtn_bias_grad(handle.raw, dyd.data_ptr(), code, B * Ho * Wo, cout, cout, db.data_ptr()))
     torch.cuda.synchronize()
@@ -166,6 +167,8 @@ def test_dgrad_and_wgrad(pkg, handle, dtype, case):
     wantb = dy.sum(dim=(0, 1, 2))
     errb = float((db.cpu().double()[:cout] - 0.25 - wantb).abs().max())
     assert errb <= tol(dtype) * max(1.0, float(wantb.abs().max()))
+    errf = float((dbf.cpu().double()[:cout] - 0.25 - wantb).abs().max())          # BiasAddGrad fused into wgrad
+    assert errf <= tol(dtype) * max(1.0, float(wantb.abs().max())) and torch.all(dbf.cpu()[cout:] == 0.25)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

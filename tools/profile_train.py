@@ -43,7 +43,9 @@ for b in bp["bops"]:
     kind = b[0]
     h, lib = eng.h, L.lib
     def run():
-        if kind == "wgrad": h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
+        if kind == "wgrad":
+            if b[4] is not None: h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], bp["ws"].data_ptr(), bp["ws"].numel()))
+            else: h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
         elif kind == "dgrad": h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
         elif kind == "bgrad": h.check(lib.rtn_bias_grad(h.raw, b[1].data_ptr(), eng.rdt, b[2], b[3], b[4], b[5].data_ptr()))
         elif kind == "padcast": h.check(lib.rtn_pad_cast_rows(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, b[3], b[4], b[5]))
@@ -51,7 +53,7 @@ for b in bp["bops"]:
         elif kind == "upbwd": h.check(lib.rtn_upsample_add_bwd(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, *b[3], b[4]))
         elif kind == "poolbwd": h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), b[1].data_ptr(), b[3].data_ptr(), eng.rdt, *b[4], 1))
     ms = timed(run)
-    label = kind + ((":" + b[-1]) if kind in ("wgrad", "dgrad") else "")
+    label = kind + ((":" + (b[3] if kind == "wgrad" else b[-1])) if kind in ("wgrad", "dgrad") else "")
     acc[label] = acc.get(label, 0) + ms
 tot = collections.Counter()
 for k, v in acc.items(): tot[k.split(":")[0]] += v
