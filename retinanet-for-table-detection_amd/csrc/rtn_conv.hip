@@ -92,6 +92,10 @@ struct KParams {
     int cshift, crun_mask, kw_inv, KW;
     int pix_stride_b, sy, sx, pad_t, pad_l;
     int out_ld, flags, vec_ok;
+    int ksplit, kt_per_split;   // split-K (128-row kernel, one group): gridDim.y slices of the K loop add into `scratch`
+    float* scratch;             // f32 [ksplit][M][scratch_ld] partial-sum slabs (plain stores; summed in slice order by the
+                                // finish kernel: bitwise reproducible, unlike float atomics)
+    int scratch_ld;
     int dense_out;   // out/res/mask are plain [M][ld] matrices: the epilogue needs no (image, pixel) split
     int dense_in;    // 1x1, stride 1, no padding on a contiguous NHWC input: row m starts at m * pix_stride
 };
@@ -421,14 +425,20 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
 
     // ---- main loop
     const int nkt = p.nkt;
-    RTN_LOAD_TILE(0);
+    int kt_lo = 0, kt_hi = nkt;
+    if (p.ksplit > 1) {
+        kt_lo = blockIdx.y * p.kt_per_split;
+        kt_hi = kt_lo + p.kt_per_split < nkt ? kt_lo + p.kt_per_split : nkt;
+        if (kt_lo >= kt_hi) return;
+    }
+    RTN_LOAD_TILE(kt_lo);
     RTN_STORE_TILE(0);
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
         // compute buffer `cur` while the loads of step kt+1 fly, then stage them into the other buffer
-        const bool more = kt + 1 < nkt;
+        const bool more = kt + 1 < kt_hi;
         if (more) RTN_LOAD_TILE(kt + 1);
         RTN_COMPUTE_TILE(cur);
         if (more) RTN_STORE_TILE(cur ^ 1);
@@ -439,6 +449,21 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
 #undef RTN_STORE_TILE
 #undef RTN_COMPUTE_TILE
 
+    if (p.ksplit > 1) {      // partial sums of this K slice -> its f32 slab; conv_splitk_finish_kernel reduces + does the epilogue
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nn = n0 + wn * WN + j * 16 + lrow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = m0 + wm * 64 + i * 16 + kq * 4 + r;
+                    if (mm < M && nn < p.scratch_ld)
+                        p.scratch[((long long)blockIdx.y * M + mm) * p.scratch_ld + nn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     // ---- epilogue: accumulators -> LDS (f32), then whole-row stores
     float* S = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -472,6 +497,36 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const KParams p) {
         const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+    }
+}
+
+// split-K finish: sum of the K-slice slabs in slice order -> standard epilogue -> out
+template <int ES>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const KParams p) {
+    const KGroup& G = p.g[0];
+    const int M = G.M, Wout = G.Wout, cells = G.Hout * Wout;
+    const int ncol = p.scratch_ld / 8;
+    const long long total = (long long)M * ncol;
+    const bool res_vec = (p.flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) && p.vec_ok;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ncol), n = (int)(i - (long long)m * ncol) * 8;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        for (int ks = 0; ks < p.ksplit; ++ks) {                    // fixed slice order
+            const float* sp = p.scratch + ((long long)ks * M + m) * p.scratch_ld + n;
+            const float4 a0 = *reinterpret_cast<const float4*>(sp);
+            const float4 a1 = *reinterpret_cast<const float4*>(sp + 4);
+            v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w;
+            v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+        }
+        if (n >= p.N) continue;
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float bv[8];
+        load_bias8(p, n, bv);
+        const RowRef r = row_ref(p, G, m, M, cells, Wout);
+        ResVec<ES> pre;
+        if (res_vec) res_prefetch<ES>(p, G, r, Wout, n, pre);
+        if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, r, n, pre);
+        epilogue_finish8<ES>(p, G, r, Wout, n, v, bv, res_vec, pre);
     }
 }
 
@@ -872,12 +927,42 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
 #undef RTN_L2
     } else {
         dim3 bdim(NT);
+        // split-K: a long K loop on a grid that cannot fill the chip (P6: 36 workgroups x 288 K steps)
+        int ksplit = 1;
+        const int ksplit_env = rtn_env_int("RTN_CONV_SPLITK", -1);
+        if (d->ngroups == 1 && grid < 128 && p.nkt >= 16 && ksplit_env != 0) {
+            ksplit = (int)((512 + grid - 1) / grid);
+            if (ksplit > p.nkt / 4) ksplit = p.nkt / 4;
+            if (ksplit_env > 1) ksplit = ksplit_env < p.nkt ? ksplit_env : p.nkt;
+            const long long slab = (long long)p.g[0].M * (((d->N + 7) / 8) * 8) * 4;
+            while (ksplit > 1 && slab * ksplit > (long long)h->splitk_bytes) --ksplit;
+            if (ksplit >= 2) {                                   // every slice must own at least one K step (it writes its whole slab)
+                const int per = (p.nkt + ksplit - 1) / ksplit;
+                ksplit = (p.nkt + per - 1) / per;
+            }
+            if (ksplit < 2 || !h->splitk_scratch) ksplit = 1;
+        }
+        if (ksplit > 1) {
+            p.ksplit = ksplit;
+            p.kt_per_split = (p.nkt + ksplit - 1) / ksplit;
+            p.scratch = h->splitk_scratch;
+            p.scratch_ld = ((d->N + 7) / 8) * 8;
+            gdim = dim3((unsigned)grid, (unsigned)ksplit);
+        }
         if (es == 2) {
             if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<2, 64>), gdim, bdim, 0, h->stream, p);
             else          hipLaunchKernelGGL((conv_igemm_kernel<2, 128>), gdim, bdim, 0, h->stream, p);
         } else {
             if (BN == 64) hipLaunchKernelGGL((conv_igemm_kernel<4, 64>), gdim, bdim, 0, h->stream, p);
             else          hipLaunchKernelGGL((conv_igemm_kernel<4, 128>), gdim, bdim, 0, h->stream, p);
+        }
+        if (ksplit > 1) {
+            RTN_CHECK_LAUNCH(h, "conv_igemm_kernel (split-K)");
+            const long long work = (long long)p.g[0].M * (p.scratch_ld / 8);
+            long long fg = (work + 255) / 256;
+            if (fg > 2048) fg = 2048;
+            if (es == 2) hipLaunchKernelGGL((conv_splitk_finish_kernel<2>), dim3((unsigned)fg), dim3(256), 0, h->stream, p);
+            else         hipLaunchKernelGGL((conv_splitk_finish_kernel<4>), dim3((unsigned)fg), dim3(256), 0, h->stream, p);
         }
     }
     RTN_CHECK_LAUNCH(h, "conv_igemm_kernel");

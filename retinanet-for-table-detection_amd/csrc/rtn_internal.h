@@ -10,6 +10,8 @@ struct rtn_ctx {
     int device;
     hipStream_t stream;
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
+    float* splitk_scratch;  // f32 slabs for split-K partial sums (library-owned scratch, 64 MiB)
+    size_t splitk_bytes;
     int num_cus;
     char err[512];
 };
