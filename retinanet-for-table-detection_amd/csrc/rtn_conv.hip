@@ -802,13 +802,34 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     long long Mtot = 0;
     for (int i = 0; i < d->ngroups; ++i) Mtot += (long long)d->g[i].Hout * d->g[i].Wout * d->batch;
     int impl = rtn_conv_impl_override();
-    if (impl == 0) {
-        // measured on MI355X (tools/ab_conv.py, same-process A/B): the 256-row kernel wins once its grid fills the
-        // 256 CUs (one workgroup per CU) and the K loop is long enough to amortise its prologue; the 128-row kernel
-        // (2 workgroups/CU) wins on small-M layers (res5*, P5..P7) and on the 1-2 step HBM-bound 1x1 layers.
-        const int bn2 = d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256);
-        const long long blocks2 = ((Mtot + BM2 - 1) / BM2) * ((d->N + bn2 - 1) / bn2);
-        impl = ((Ktot * es) >= 1024 && blocks2 >= 200 && d->N != 128) ? 2 : 1;
+    int bn2 = d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256);   // widest 256-row tile that N fills
+    {
+        // Tile choice, fitted to the same-process sweep in profiles/r1_conv_tile_sweep.txt (tools/ab_conv.py):
+        //  * the 256-row LDS-DMA kernel runs one workgroup per CU, so its time is (grid rounded up to whole
+        //    rounds of CUs) x (time of one tile); one 256x{64,128,256} tile costs 1 : 2.02 : 3.44 on a long K loop.
+        //    Wide tiles therefore only pay when the grid stays many rounds deep (the head towers);
+        //  * on short K loops the epilogue and HBM dominate and the narrow tile (more workgroups in flight) wins;
+        //  * the 128-row register-staged kernel (3 workgroups/CU) keeps the <=64-channel layers that are pure
+        //    streaming: 1x1 with K >= 256 (res2*_branch2a) and the grouped head outputs.
+        const long long mt2 = (Mtot + BM2 - 1) / BM2;
+        const int cus = h->num_cus > 0 ? h->num_cus : 256;
+        if (Ktot * es >= 2048 && d->N > 64) {
+            const int cand[3] = {64, 128, 256};
+            const double wgt[3] = {1.0, 2.02, 3.44};
+            const int widest = bn2;
+            double best = 0;
+            for (int c = 0; c < 3 && cand[c] <= widest; ++c) {
+                const long long grid = mt2 * ((d->N + cand[c] - 1) / cand[c]);
+                const double cost = (double)((grid + cus - 1) / cus) * wgt[c];
+                if (c == 0 || cost < best * 0.97) { best = cost; bn2 = cand[c]; }   // ties go to the narrower tile
+            }
+        } else if (d->N > 64) {
+            bn2 = 64;
+        }
+        if (impl == 0) {
+            const bool stream64 = d->N <= 64 && ((d->KH * d->KW == 1 && Ktot * es >= 512) || d->ngroups > 1);
+            impl = stream64 ? 1 : 2;
+        }
     }
     const int TM = impl == 2 ? BM2 : BM;
     for (int i = 0; i < d->ngroups; ++i) {
@@ -873,7 +894,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     }
     (void)out_f32;
     if ((d->flags & RTN_CONV_RELU_MASK) && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv: RELU_MASK needs N, out_ld, strides multiples of 8");
-    const int BN = impl == 2 ? (d->N <= 64 ? 64 : (d->N <= 128 ? 128 : 256)) : (d->N <= 64 ? 64 : 128);
+    int BN = impl == 2 ? bn2 : (d->N <= 64 ? 64 : 128);
+    if (impl == 2) {
+        const int bn_env = rtn_env_int("RTN_CONV_BN2", 0);   // A/B override of the 256-row kernel's tile width
+        if ((bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
+    }
     p.w = (const char*)d->w;
     p.bias = d->bias;
     if ((long long)d->w_rows * Ktot * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "conv: weights exceed the 4 GiB buffer-descriptor range");
