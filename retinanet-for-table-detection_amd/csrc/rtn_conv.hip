@@ -61,6 +61,16 @@ __device__ __forceinline__ void dma16_to_lds(const i32x4& srd, unsigned voff, un
                  : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait until at most `stages` x PIECES of this wave's newest vector-memory operations are still in flight (vmcnt
+// retires in order): the older stages' LDS-DMA pieces have landed.  `stages` is wave-uniform.
+template <int PIECES>
+__device__ __forceinline__ void dma_wait_keep(int stages) {
+    static_assert(3 * PIECES < 64, "vmcnt is a 6-bit counter");
+    if (stages <= 0)      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+    else if (stages == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PIECES) : "memory");
+    else                  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * PIECES) : "memory");
+}
 
 struct KGroup {
     const char* in;
@@ -98,6 +108,8 @@ struct KParams {
     int scratch_ld;
     int dense_out;   // out/res/mask are plain [M][ld] matrices: the epilogue needs no (image, pixel) split
     int dense_in;    // 1x1, stride 1, no padding on a contiguous NHWC input: row m starts at m * pix_stride
+    int nstages;     // 256-row kernel: depth of the LDS staging ring (1..4), sized by the launcher
+    int korder_chunks, korder_kw;   // 256-row kernel: K-step visiting order (see KOrder in the kernel); {nkt, 1} = in order
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -553,8 +565,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
     constexpr int SLDW = WN + 4;
     constexpr int EPI_WAVE_BYTES = 32 * SLDW * 4;
     constexpr int EPI_BYTES = 8 * EPI_WAVE_BYTES;
-    constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    constexpr int SB = A_BYTES + B_BYTES;        // one stage: A image then B image
+    // dynamic LDS: conv2_lds_bytes() stages (1 when the K loop has a single step, else 2), never less than EPI_BYTES
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(STAGE_BYTES == 2 * SB && EPI_BYTES <= 160 * 1024 && STAGE_BYTES <= 160 * 1024, "LDS budget");
 
     int wg;
     {
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 
     // One staging piece (1 KiB per wave): D < 4 -> A row-block D of this wave, else B row-block D-4.
 #define RTN_TAPS(KT)                                                                                                \
-    const int kb_ = (KT) * 128 + c * 16;                                                                            \
+    const int kb_ = (KT) * 128 + c * 16;   /* KT = position of the step in K (see KOrder) */                        \
     const int k0_ = kb_ >> ESH;                                                                                     \
     const int kpos_ = k0_ >> p.cshift;                                                                              \
     const int coff_ = k0_ & p.crun_mask;                                                                            \
@@ -629,10 +643,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
             const int iy_ = iy0[(D) & 3] + kh_, ix_ = ix0[(D) & 3] + kw_;                                           \
             const bool ok_ = (unsigned)iy_ < (unsigned)Hin && (unsigned)ix_ < (unsigned)Win;                        \
             dma16_to_lds(in_srd, ok_ ? rowbase[(D) & 3] + delta_ : OOB_OFFSET,                                      \
-                         lds_base + (unsigned)((BUF) * A_BYTES + wave * 1024 + ((D) & 3) * 8192));                  \
+                         lds_base + (unsigned)((BUF) * SB + wave * 1024 + ((D) & 3) * 8192));                       \
         } else {                                                                                                    \
             dma16_to_lds(w_srd, wk_ + (unsigned)((D) - 4) * wstep,                                                  \
-                         lds_base + (unsigned)(2 * A_BYTES + (BUF) * B_BYTES + wave * 1024 + ((D) - 4) * 8192));    \
+                         lds_base + (unsigned)((BUF) * SB + A_BYTES + wave * 1024 + ((D) - 4) * 8192));             \
         }                                                                                                           \
     }
 
@@ -649,31 +663,47 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Order in which the K steps are visited.  K is laid out (kh, kw, c); with `p.korder_chunks` = 128-byte chunks per
+    // tap the loop walks a kernel row as (chunk, kw) instead of (kw, chunk): the three kw taps of one channel chunk
+    // run back to back, and they read the same input lines shifted by one pixel, so two of every three A stagings
+    // hit the L1/L2 lines the previous step just pulled.  f32 accumulation order changes with it (deterministic).
+    int ko_row = 0, ko_cc = 0, ko_kw = 0;
+    const int ko_nchunk = p.korder_chunks, ko_kw_n = p.korder_kw;
+#define RTN_KO_POS() ((ko_row * ko_kw_n + ko_kw) * ko_nchunk + ko_cc)
+#define RTN_KO_NEXT()                                                                                               \
+    do {                                                                                                            \
+        if (++ko_kw == ko_kw_n) { ko_kw = 0; if (++ko_cc == ko_nchunk) { ko_cc = 0; ++ko_row; } }                   \
+    } while (0)
+
     constexpr int NJ = NI < 4 ? NI : 4;           // B fragments held at once
     constexpr int ND = 4 + NBI;                   // staging pieces per wave per K step
     constexpr int NS = 2 * (NI / NJ) * 2;         // MFMA groups per K step = slots the pieces are spread over
 
+    // Staging ring of `nst` stages: steps kt+1 .. kt+nst-1 are in flight while step kt is multiplied, so a step
+    // costs max(MFMA time, DMA latency / (nst-1)) instead of their sum on the narrow tiles.
     const int nkt = p.nkt;
-    {
-        RTN_TAPS(0);
+    const int nst = p.nstages;
+    for (int s_ = 0; s_ < nst - 1 && s_ < nkt; ++s_) {
+        RTN_TAPS(RTN_KO_POS());
 #pragma unroll
-        for (int d = 0; d < ND; ++d) RTN_DMA(0, d);
+        for (int d = 0; d < ND; ++d) RTN_DMA(s_, d);
+        RTN_KO_NEXT();
     }
-    dma_wait_all();
+    dma_wait_keep<ND>((nst - 1 < nkt ? nst - 1 : nkt) - 1);
     __syncthreads();
-    int cur = 0;
+    int cur = 0;                     // kt % nst
+    int nxt = nst - 1;               // (kt + nst - 1) % nst: the buffer step kt-1 just released
 #pragma unroll 1
     for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        RTN_TAPS(kt + 1);
-        const char* A_ = lds + cur * A_BYTES + a_row_off;
-        const char* B_ = lds + 2 * A_BYTES + cur * B_BYTES + b_row_off;
+        const bool more = kt + nst - 1 < nkt;
+        RTN_TAPS(RTN_KO_POS());
+        RTN_KO_NEXT();
+        const char* A_ = lds + cur * SB + a_row_off;
+        const char* B_ = lds + cur * SB + A_BYTES + b_row_off;
         if (!IL && more) {
 #pragma unroll
-            for (int d = 0; d < ND; ++d) RTN_DMA(cur ^ 1, d);
+            for (int d = 0; d < ND; ++d) RTN_DMA(nxt, d);
         }
-        // MFMAs of step kt with the DMA issues of step kt+1 interleaved between the MFMA groups: the matrix pipe
-        // keeps running while this wave issues its staging pieces (both waves of a SIMD run this in lockstep).
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int rd = ks ? rd1 : rd0;
@@ -692,19 +722,24 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #pragma unroll
                         for (int j_ = 0; j_ < NJ; ++j_) mma_step<ES>(acc[i_][jh + j_], a_[i_], b_[j_]);
                     const int slot = (ks * (NI / NJ) + jh / NJ) * 2 + ih;
-                    if (IL && more) {
+                    if (IL && more) {     // A/B variant: DMA issues spread between the MFMA groups (measured slower)
 #pragma unroll
-                        for (int d = slot * ND / NS; d < (slot + 1) * ND / NS; ++d) RTN_DMA(cur ^ 1, d);
+                        for (int d = slot * ND / NS; d < (slot + 1) * ND / NS; ++d) RTN_DMA(nxt, d);
                     }
                 }
             }
         }
-        dma_wait_all();                                     // this wave's pieces of step kt+1 have landed ...
-        __syncthreads();                                    // ... and so have everyone else's; buffer `cur` is free
-        cur ^= 1;
+        // step kt+1 must have landed; the stages after it (up to the last one issued) may stay in flight
+        const int last_issued = kt + nst - 1 < nkt - 1 ? kt + nst - 1 : nkt - 1;
+        dma_wait_keep<ND>(last_issued - (kt + 1));
+        __syncthreads();                                    // everyone's pieces of kt+1 landed; buffer `cur` is free
+        cur = cur + 1 == nst ? 0 : cur + 1;
+        nxt = nxt + 1 == nst ? 0 : nxt + 1;
     }
 #undef RTN_TAPS
 #undef RTN_DMA
+#undef RTN_KO_POS
+#undef RTN_KO_NEXT
 
     // ---- wave-private epilogue: 2 halves of 32 rows through this wave's LDS slice
     float* S = reinterpret_cast<float*>(lds + wave * EPI_WAVE_BYTES);
@@ -828,7 +863,10 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
         }
         if (impl == 0) {
             const bool stream64 = d->N <= 64 && ((d->KH * d->KW == 1 && Ktot * es >= 512) || d->ngroups > 1);
-            impl = stream64 ? 1 : 2;
+            // tiny-M, long-K layers (P6, P7): only the 128-row kernel has the split-K path
+            const long long grid1 = ((Mtot + BM - 1) / BM) * ((d->N + 127) / 128);
+            const bool splitk = d->ngroups == 1 && grid1 < 128 && Ktot * es / 128 >= 16;
+            impl = (stream64 || splitk) ? 1 : 2;
         }
     }
     const int TM = impl == 2 ? BM2 : BM;
@@ -942,14 +980,44 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     if (impl == 2) {
         dim3 bdim(NT2);
         const bool il = rtn_env_int("RTN_CONV_IL", 0) != 0;
+        // LDS: one stage when the K loop is a single step (the streaming 1x1 layers: more workgroups per CU), else two
+        // LDS ring depth: as many stages as fit 160 KB (64-wide: 3 by default, 128-wide: 3, 256-wide: 2), never more
+        // than the K loop has steps.  RTN_CONV_STAGES=1..4 overrides (A/B knob).
+        const unsigned epib = 8u * 32u * (unsigned)(BN / 2 + 4) * 4u;     // the wave-private epilogue slices (EPI_BYTES)
+        const unsigned sb = (unsigned)(BM2 + BN) * 128u;
+        int nst = 2;   // measured: deeper rings lose (they cost the second resident workgroup on the 64-wide tile)
+        const int nst_env = rtn_env_int("RTN_CONV_STAGES", 0);
+        if (nst_env >= 1 && nst_env <= 4) nst = nst_env;
+        while (nst > 1 && (unsigned)nst * sb > 160u * 1024u) --nst;
+        if (nst > p.nkt) nst = p.nkt;
+        if (nst < 2 && p.nkt > 1) nst = 2;
+        // K-step order: (chunk, kw) inside a kernel row when a tap spans whole 128-byte chunks (RTN_CONV_KORDER=0: in order)
+        p.korder_chunks = p.nkt; p.korder_kw = 1;
+        if (d->KW > 1 && (d->Crun * es) % 128 == 0 && rtn_env_int("RTN_CONV_KORDER", 1) != 0) {
+            p.korder_chunks = d->Crun * es / 128;
+            p.korder_kw = d->KW;
+        }
+        p.nstages = nst < 2 ? 2 : nst;      // a single-step K loop never touches its second buffer
+        unsigned ldsb = (unsigned)nst * sb;
+        if (ldsb < epib) ldsb = epib;
+#define RTN_L2K(E, B, I)                                                                                 \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm2_kernel<E, B, I>,                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_igemm2_kernel<E, B, I>), gdim, bdim, ldsb, h->stream, p);               \
+    } while (0)
 #define RTN_L2(E, B)                                                                                     \
     do {                                                                                                 \
-        if (il) hipLaunchKernelGGL((conv_igemm2_kernel<E, B, true>), gdim, bdim, 0, h->stream, p);       \
-        else    hipLaunchKernelGGL((conv_igemm2_kernel<E, B, false>), gdim, bdim, 0, h->stream, p);      \
+        if (il) RTN_L2K(E, B, true); else RTN_L2K(E, B, false);                                          \
     } while (0)
         if (es == 2) { if (BN == 64) RTN_L2(2, 64); else if (BN == 128) RTN_L2(2, 128); else RTN_L2(2, 256); }
         else         { if (BN == 64) RTN_L2(4, 64); else if (BN == 128) RTN_L2(4, 128); else RTN_L2(4, 256); }
 #undef RTN_L2
+#undef RTN_L2K
     } else {
         dim3 bdim(NT);
         // split-K: a long K loop on a grid that cannot fill the chip (P6: 36 workgroups x 288 K steps)

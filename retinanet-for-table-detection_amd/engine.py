@@ -12,6 +12,7 @@ convolution epilogues; the five pyramid levels of a head layer run as ONE groupe
 import ctypes as C
 
 import numpy as np
+import os
 import torch
 
 from . import _lib as L
@@ -82,6 +83,8 @@ class Engine:
         self.plans = {}
         self.state = None
         self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
+        self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # head towers on two HIP streams
+        self._side = None
 
     # ------------------------------------------------------------------ weights
     def load_state(self, state):
@@ -259,9 +262,11 @@ class Engine:
         regression = buf(B, N, 4, dtype=torch.float32)
         classification = buf(B, N, self.K, dtype=torch.float32)
         # ---- heads: every layer is ONE grouped launch over the five levels (weights shared, :217)
+        tower_ranges = []
         for prefix, out_t, per_anchor, last_flags in (("pyramid_regression", regression, 4, L.CONV_OUT_F32),
                                                       ("pyramid_classification", classification, self.K,
                                                        L.CONV_OUT_F32 | L.CONV_SIGMOID)):
+            tower_start = len(ops)
             cur = pyr
             for i in range(4):
                 nxt = [buf(B, *hw(p), 256) for p in pyr]
@@ -271,8 +276,9 @@ class Engine:
             groups = [self._group(ci, out_t, *hw(ci), out_off=cfg.anchor_off[l] * per_anchor, out_img_stride=N * per_anchor)
                       for l, ci in enumerate(cur)]
             ops.append(self._conv(prefix, groups, B, pad=(1, 1), flags=last_flags, out_ld=self.A * per_anchor))
+            tower_ranges.append((tower_start, len(ops)))
         ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
-        plan = {"ops": ops, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        plan = {"ops": ops, "towers": tower_ranges, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -298,8 +304,33 @@ class Engine:
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)
         self._bind_stream()
-        for op in plan["ops"]:
+        ops = plan["ops"]
+        if not self.two_streams:
+            for op in ops:
+                self._run_op(op, images)
+            return plan["regression"], plan["classification"]
+        # The two head towers are independent chains over the same pyramid (model/defineModel.py:217-249): the
+        # classification tower runs on a side stream so each tower's partly filled last round of workgroups
+        # (699 tiles on 256 CUs) and its store burst overlap the other tower's work.
+        (r0, r1), (c0, c1) = plan["towers"]
+        for op in ops[:r0]:
             self._run_op(op, images)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+        self._fork.record(main)
+        self._side.wait_event(self._fork)
+        for i in range(max(r1 - r0, c1 - c0)):
+            if r0 + i < r1:
+                self.h.set_stream(main.cuda_stream)
+                self._run_op(ops[r0 + i], images)
+            if c0 + i < c1:
+                self.h.set_stream(self._side.cuda_stream)
+                self._run_op(ops[c0 + i], images)
+        self._join.record(self._side)
+        main.wait_event(self._join)
+        self.h.set_stream(main.cuda_stream)
         return plan["regression"], plan["classification"]
 
     def _run_op(self, op, images):
