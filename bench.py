@@ -52,6 +52,34 @@ def conv_flops(op_desc, batch):
     return 2.0 * m * d.N * k_true
 
 
+def conv_bytes(op_desc, batch):
+    """Algorithmic HBM bytes of one conv launch: every input, weight, residual element read once, every output written once."""
+    d = op_desc
+    es = 4 if d.dtype == 1 else 2
+    out_es = 4 if (d.flags & 0x10) else es
+    total = d.N * d.KH * d.KW * d.Crun * es
+    for i in range(d.ngroups):
+        g = d.g[i]
+        total += batch * g.Hin * g.Win * d.pix_stride * es
+        total += batch * g.Hout * g.Wout * d.N * out_es
+        if d.flags & 0x04:
+            total += batch * g.Hout * g.Wout * d.N * es
+        if d.flags & 0x08:
+            total += batch * g.Hres * g.Wres * d.N * es
+    return float(total)
+
+
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
+    rocprofv3 --pmc in separate passes, collected on this same bench command); None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["conv_total"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(torch, state, threads):
     import numpy as np
     from oracle import ref_numpy as R
@@ -223,10 +251,17 @@ def main():
         other_ms = sum(ms for kind, ms in per_op_ms if kind != "conv") / reps
         achieved = flops_step / (conv_ms * 1e-3) / 1e12
         ncand = int((plan["classification"] > 0.05).sum().item())
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16>", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+        bytes_step = sum(conv_bytes(op[1], BATCH) for op in conv_ops)
+        pmc = pmc_traffic()
+        roofline = {"bound": "mfma", "kernel": "conv_igemm2_kernel/conv_igemm_kernel<bf16> (all conv launches of a step)",
+                    "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
+                    "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None),
+                    "traffic_source": ("profiles/r1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if pmc else None),
+                    "algorithmic_bytes_per_launch": bytes_step / len(conv_ops),
                     "launches_per_step": len(conv_ops), "avg_launch_ms": conv_ms / len(conv_ops),
-                    "flop_per_step": flops_step, "conv_ms_per_step": conv_ms, "non_conv_ms_per_step": other_ms}
+                    "flop_per_step": flops_step, "flop_per_launch": flops_step / len(conv_ops),
+                    "conv_ms_per_step": conv_ms, "non_conv_ms_per_step": other_ms}
         out = {"metric": "images/sec RetinaNet R50-FPN 800x1333 inference", "value": value, "unit": "images/sec",
                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -1033,12 +1033,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
                 const int per = (p.nkt + ksplit - 1) / ksplit;
                 ksplit = (p.nkt + per - 1) / per;
             }
-            if (ksplit < 2 || !h->splitk_scratch) ksplit = 1;
+            float* scratch = ksplit >= 2 ? rtn_splitk_scratch(h) : nullptr;
+            if (ksplit < 2 || !scratch) ksplit = 1;
+            p.scratch = scratch;
         }
         if (ksplit > 1) {
             p.ksplit = ksplit;
             p.kt_per_split = (p.nkt + ksplit - 1) / ksplit;
-            p.scratch = h->splitk_scratch;
             p.scratch_ld = ((d->N + 7) / 8) * 8;
             gdim = dim3((unsigned)grid, (unsigned)ksplit);
         }

@@ -15,7 +15,7 @@ extern "C" int rtn_create(rtn_handle_t* out, int device) {
     if (e == hipSuccess) e = hipMalloc(&h->zero_page, 256);
     if (e == hipSuccess) e = hipMemset(h->zero_page, 0, 256);
     h->splitk_bytes = 64u << 20;
-    if (e == hipSuccess) e = hipMalloc((void**)&h->splitk_scratch, h->splitk_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->scratch[0].ptr, h->splitk_bytes);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -30,7 +30,8 @@ extern "C" int rtn_create(rtn_handle_t* out, int device) {
 extern "C" int rtn_destroy(rtn_handle_t h) {
     if (!h) return RTN_EINVAL;
     if (h->zero_page) (void)hipFree(h->zero_page);
-    if (h->splitk_scratch) (void)hipFree(h->splitk_scratch);
+    for (int i = 0; i < rtn_ctx::kScratchSlots; ++i)
+        if (h->scratch[i].ptr) (void)hipFree(h->scratch[i].ptr);
     delete h;
     return RTN_OK;
 }

@@ -278,7 +278,8 @@ class Engine:
             ops.append(self._conv(prefix, groups, B, pad=(1, 1), flags=last_flags, out_ld=self.A * per_anchor))
             tower_ranges.append((tower_start, len(ops)))
         ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
-        plan = {"ops": ops, "towers": tower_ranges, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        sched = self._schedule(ops)
+        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -286,6 +287,74 @@ class Engine:
                 "labels": torch.empty(B, L.RTN_MAX_DET, dtype=torch.int32, device=dev)}
         self.plans[key] = plan
         return plan
+
+    # ------------------------------------------------------------------ lanes
+    @staticmethod
+    def _op_io(op):
+        """(tensors read, tensors written) of a plan op, as data pointers."""
+        kind = op[0]
+        if kind == "conv":
+            m = op[3]
+            reads = [t.data_ptr() for t in m["xs"]] + [t.data_ptr() for t in m["res"] if t is not None]
+            return reads, [t.data_ptr() for t in m["ys"]]
+        if kind == "pack":
+            return [], [op[1].data_ptr()]
+        if kind == "pool":
+            return [op[1].data_ptr()], [op[2].data_ptr(), op[4].data_ptr()]
+        if kind == "relu":
+            return [op[1].data_ptr()], [op[2].data_ptr()]
+        raise RuntimeError("unknown op %r" % (kind,))
+
+    @staticmethod
+    def _lane_of(op):
+        """HIP stream lane of an op.  The graph is a chain except where the reference's model forks
+        (model/defineModel.py:183-249): the projection shortcut of a stage's first block (branch1, beside branch2a/2b),
+        the P6 -> P7 and P5 / P4 branches of the pyramid (beside the top-down C4/C3 path) and the two head towers.  Those
+        run on side lanes so that their launch latency and partly filled last rounds of workgroups overlap other work."""
+        if op[0] == "relu":
+            return 1                                              # between P6 and P7
+        if op[0] != "conv":
+            return 0
+        name = op[2]
+        if name.endswith("_branch1") or name in ("P6", "P7"):
+            return 1
+        if name in ("P5", "P4"):
+            return 2
+        if name.startswith("pyramid_classification"):
+            return 1
+        return 0
+
+    def _schedule(self, ops):
+        """Per op: (lane, [indices of ops on OTHER lanes whose completion it must wait for], needs_event).  Dependencies are
+        read-after-write and write-after-write on the plan's buffers (every tensor of a plan is written by exactly one op
+        of a forward pass, so there are no write-after-read hazards inside a pass; passes are joined on lane 0)."""
+        lanes = [self._lane_of(op) for op in ops]
+        writer = {}
+        waits = []
+        for i, op in enumerate(ops):
+            reads, writes = self._op_io(op)
+            deps = set()
+            for ptr in reads + writes:
+                j = writer.get(ptr)
+                if j is not None and lanes[j] != lanes[i]:
+                    deps.add(j)
+            waits.append(sorted(deps))
+            for ptr in writes:
+                writer[ptr] = i
+        # per (consumer lane, producer lane) only the latest producer matters: streams are in order
+        slim = []
+        for i, deps in enumerate(waits):
+            latest = {}
+            for j in deps:
+                latest[lanes[j]] = max(latest.get(lanes[j], -1), j)
+            slim.append(sorted(latest.values()))
+        needs_event = set(j for deps in slim for j in deps)
+        last_on_lane = {}
+        for i, ln in enumerate(lanes):
+            last_on_lane[ln] = i
+        joins = sorted(i for ln, i in last_on_lane.items() if ln != 0)
+        needs_event.update(joins)
+        return {"lanes": lanes, "waits": slim, "events": needs_event, "joins": joins, "nlanes": max(lanes) + 1}
 
     # ------------------------------------------------------------------ run
     def _bind_stream(self):
@@ -309,27 +378,30 @@ class Engine:
             for op in ops:
                 self._run_op(op, images)
             return plan["regression"], plan["classification"]
-        # The two head towers are independent chains over the same pyramid (model/defineModel.py:217-249): the
-        # classification tower runs on a side stream so each tower's partly filled last round of workgroups
-        # (699 tiles on 256 CUs) and its store burst overlap the other tower's work.
-        (r0, r1), (c0, c1) = plan["towers"]
-        for op in ops[:r0]:
-            self._run_op(op, images)
+        sched = plan["sched"]
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
-        self._fork.record(main)
-        self._side.wait_event(self._fork)
-        for i in range(max(r1 - r0, c1 - c0)):
-            if r0 + i < r1:
-                self.h.set_stream(main.cuda_stream)
-                self._run_op(ops[r0 + i], images)
-            if c0 + i < c1:
-                self.h.set_stream(self._side.cuda_stream)
-                self._run_op(ops[c0 + i], images)
-        self._join.record(self._side)
-        main.wait_event(self._join)
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        streams = [main] + self._side
+        lanes, waits = sched["lanes"], sched["waits"]
+        events = plan.setdefault("events", {i: torch.cuda.Event() for i in sched["events"]})
+        fork = plan.setdefault("fork", torch.cuda.Event())
+        fork.record(main)                                    # side lanes start after everything queued before this pass
+        for st in streams[1:sched["nlanes"]]:
+            st.wait_event(fork)
+        bound = None
+        for i, op in enumerate(ops):
+            st = streams[lanes[i]]
+            for j in waits[i]:
+                st.wait_event(events[j])
+            if bound is not st:
+                self.h.set_stream(st.cuda_stream)
+                bound = st
+            self._run_op(op, images)
+            if i in events:
+                events[i].record(st)
+        for j in sched["joins"]:
+            main.wait_event(events[j])
         self.h.set_stream(main.cuda_stream)
         return plan["regression"], plan["classification"]
 

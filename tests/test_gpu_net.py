@@ -129,3 +129,26 @@ def test_backbone_validation(pkg):
     E, _ = mods(pkg)
     with pytest.raises(ValueError):
         E.Engine("vgg16", 1, 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,B,hw", [("bf16", 2, (320, 416)), ("f32", 1, (256, 256)), ("bf16", 3, (512, 672))])
+def test_stream_lanes_give_the_single_stream_bits(pkg, state, dtype, B, hw):
+    """The forward pass runs the graph's forks (branch1, P6/P7, P5/P4, the classification tower) on side HIP streams with
+    events on every cross-lane read (engine.Engine._schedule).  A missing dependency or a shared scratch buffer shows up
+    as different bits: compare with the single-stream order, several passes back to back."""
+    E, _ = mods(pkg)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, hw[0], hw[1], 3, generator=g) * 2 - 1).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype=dtype)
+    eng.load_state(state)
+    eng.two_streams = False
+    r0, c0 = [t.clone() for t in eng.forward(x)]
+    torch.cuda.synchronize()
+    eng.two_streams = True
+    sched = eng._plan(B, hw[0], hw[1])["sched"]
+    assert sched["nlanes"] >= 3 and len(sched["joins"]) >= 2
+    for _ in range(4):
+        r1, c1 = eng.forward(x)
+        torch.cuda.synchronize()
+        assert torch.equal(r0, r1) and torch.equal(c0, c1)
