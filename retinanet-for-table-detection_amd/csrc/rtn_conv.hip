@@ -99,7 +99,7 @@ struct KParams {
     unsigned w_bytes;
     int ngroups, ntiles_n;
     int N, Kbytes, nkt;
-    int cshift, crun_mask, kw_inv, KW;
+    int cshift, crun_mask, kw_inv, KW, KH;
     int pix_stride_b, sy, sx, pad_t, pad_l;
     int out_ld, flags, vec_ok;
     int ksplit, kt_per_split;   // split-K (128-row kernel, one group): gridDim.y slices of the K loop add into `scratch`
@@ -780,6 +780,246 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Third generation, for stride-1 'same' KHxKW convolutions (every 3x3 layer of the network): the 256-row kernel with the
+// input taps of one kernel row sharing ONE staged image.  For a fixed (kh, channel chunk) the KW taps read the same input
+// lines shifted by one pixel, so the kernel stages a HALO of 256 consecutive input pixels (flat NHWC index) once and the
+// tap kw multiplies LDS rows [kw, kw+256): A traffic L2->LDS drops by KW (the 64-wide tiles were bound by exactly that
+// traffic: 40 KB per K step, now 18.7 KB).  The tile advances by TM = 256-(KW-1) output pixels so the halo is exactly 32
+// staging pieces (its last KW-1 MFMA rows are computed and dropped).
+//   * rows whose vertical tap leaves the image are zero-filled at staging time (range-checked DMA, as before); the test
+//     is on the halo pixel's own image row iy0: 0 <= iy0 + kh - pad_t < H, which is the consumer's test because every
+//     consumer of that halo row that is not edge-masked sits on the same image row;
+//   * the horizontal edge (ox + kw - pad_l outside [0, W)) depends on the consumer: the A fragment of such a row is
+//     zeroed in registers (4 v_cndmask per fragment on the kw != centre steps).
+// K is walked (kh, chunk, kw) - the weights keep their (kh, kw, c) layout, the B tile of a step is column block
+// ((kh*KW + kw)*chunks + chunk).
+template <int ES, int BN>
+__global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
+    constexpr int WN = BN / 2;
+    constexpr int NI = WN / 16;
+    constexpr int MI = 4;
+    constexpr int NBI = BN / 64;                 // B row-blocks (8 rows) staged per wave
+    constexpr int A_BYTES = BM2 * 128, B_BYTES = BN * 128;
+    constexpr int B_BASE = 2 * A_BYTES;
+    constexpr int SLDW = WN + 4;
+    constexpr int EPI_WAVE_BYTES = 32 * SLDW * 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 A halos, 2 B tiles (>= the epilogue slices)
+
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mtile_g = wg / p.ntiles_n;
+    const int ntile = wg - mtile_g * p.ntiles_n;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < RTN_MAX_GROUPS; ++i)
+        if (i < p.ngroups && mtile_g >= p.g[i].tile_begin) gi = i;
+    const KGroup& G = p.g[gi];
+    const int KWn = p.KW;
+    const int TM = BM2 - (KWn - 1);
+    const int m0 = (mtile_g - G.tile_begin) * TM;
+    const int n0 = ntile * BN;
+    const int M = G.M;
+    const int Wout = G.Wout;
+    const int cells = G.Hout * Wout;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lr = lane >> 3;
+    const int c = (lane & 7) ^ lr;                    // source chunk of this lane (swizzle on the source)
+
+    const i32x4 in_srd = make_srd(G.in, G.in_bytes);
+    const i32x4 w_srd = make_srd(p.w, p.w_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- halo rows staged by this lane: piece i of the wave is row-block (i*8 + wave), row h = block*8 + lr
+    unsigned hbase[4];      // byte offset of the halo pixel (kh = pad_t row), + chunk
+    int hiy[4];             // its image row, or far negative when the pixel does not exist
+    const int Hin = G.Hin;
+    const long long total_px = (long long)(M);        // B * cells (Hout == Hin, Wout == Win)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = (i * 8 + wave) * 8 + lr;
+        const long long f = (long long)m0 + h - p.pad_l;
+        if (f >= 0 && f < total_px) {
+            const int fi = (int)f;
+            const int b = fi / cells;
+            const int rem = fi - b * cells;
+            hiy[i] = rem / Wout;
+            hbase[i] = (unsigned)(f * p.pix_stride_b) + (unsigned)c * 16u;
+        } else {
+            hiy[i] = -(1 << 28);
+            hbase[i] = 0;
+        }
+    }
+    const unsigned wbase = (unsigned)(n0 + wave * 8 + lr) * (unsigned)p.Kbytes + (unsigned)c * 16u;
+    const unsigned wstep = 64u * (unsigned)p.Kbytes;
+    const int in_row_stride_b = G.in_row_stride_b;
+    const int nchunk = p.korder_chunks;               // 128-byte chunks per tap
+
+    // ---- fragment rows of this lane and their horizontal edge masks: bit (i*4 + kw) set = tap kw leaves the image
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 15, kq = lane >> 4;
+    unsigned emask = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lrow;
+        const int mc = m < M ? m : M - 1;
+        const int rem = mc % cells;
+        const int ox = rem % Wout;
+        for (int kw = 0; kw < KWn; ++kw)
+            if ((unsigned)(ox + kw - p.pad_l) >= (unsigned)Wout) emask |= 1u << (i * 4 + kw);
+    }
+    const int a_row = wm * 64 + lrow;
+    const int b_row_off = (wn * WN + lrow) * 128;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NJ = NI < 4 ? NI : 4;
+
+    // group = (kh, chunk); step = (group, kw)
+#define RTN_A_STAGE(ABUF, KH_, CC_)                                                                                 \
+    {                                                                                                               \
+        const int dy_ = (KH_) - p.pad_t;                                                                            \
+        const unsigned delta_ = (unsigned)(dy_ * in_row_stride_b + (CC_) * 128);                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+            const bool ok_ = (unsigned)(hiy[i_] + dy_) < (unsigned)Hin;                                             \
+            dma16_to_lds(in_srd, ok_ ? hbase[i_] + delta_ : OOB_OFFSET,                                             \
+                         lds_base + (unsigned)((ABUF) * A_BYTES + wave * 1024 + i_ * 8192));                        \
+        }                                                                                                           \
+    }
+#define RTN_B_STAGE(BBUF, KH_, CC_, KW_)                                                                            \
+    {                                                                                                               \
+        const unsigned wk_ = wbase + (unsigned)((((KH_) * KWn + (KW_)) * nchunk + (CC_)) * 128);                    \
+        _Pragma("unroll") for (int d_ = 0; d_ < NBI; ++d_)                                                          \
+            dma16_to_lds(w_srd, wk_ + (unsigned)d_ * wstep,                                                         \
+                         lds_base + (unsigned)(B_BASE + (BBUF) * B_BYTES + wave * 1024 + d_ * 8192));               \
+    }
+
+    // B ring of `nbst` stages (2 or 3): the B tile of step kt + nbst - 1 is staged while step kt is multiplied.
+    const int nkt = p.nkt;
+    const int nbst = p.nstages;
+    int kh = 0, cc = 0, kw = 0;                       // the step being multiplied
+    int nkh = 0, ncc = 0, nkw = 0;                    // the step whose B tile is staged next
+    int abuf = 0, bcur = 0, bnxt = 0;
+    RTN_A_STAGE(0, 0, 0);
+    for (int s_ = 0; s_ < nbst - 1 && s_ < nkt; ++s_) {
+        RTN_B_STAGE(bnxt, nkh, ncc, nkw);
+        if (++nkw == KWn) { nkw = 0; if (++ncc == nchunk) { ncc = 0; ++nkh; } }
+        bnxt = bnxt + 1 == nbst ? 0 : bnxt + 1;
+    }
+    if (nbst == 3 && nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBI) : "memory");     // halo + B(0) landed
+    else                      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bool a_prev = false;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + nbst - 1 < nkt;
+        bool a_now = false;
+        if (more) {
+            RTN_B_STAGE(bnxt, nkh, ncc, nkw);
+            if (++nkw == KWn) { nkw = 0; if (++ncc == nchunk) { ncc = 0; ++nkh; } }
+            bnxt = bnxt + 1 == nbst ? 0 : bnxt + 1;
+        }
+        if (kw == 0) {                                // first step of a group: stage the NEXT group's halo behind the B tile
+            int gkh = kh, gcc = cc + 1;
+            if (gcc == nchunk) { gcc = 0; ++gkh; }
+            if (gkh < p.KH) { RTN_A_STAGE(abuf ^ 1, gkh, gcc); a_now = true; }
+        }
+        const int rr = a_row + kw;                    // LDS row of this lane's first fragment row for tap kw
+        const int swz = rr & 7;
+        const char* A_ = lds + abuf * A_BYTES + rr * 128;
+        const char* B_ = lds + B_BASE + bcur * B_BYTES + b_row_off;
+        const unsigned em = emask >> kw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int rdA = ((ks * 4 + kq) ^ swz) << 4;
+            const int rdB = ((ks * 4 + kq) ^ (lrow & 7)) << 4;
+            uint4 a_[MI];
+#pragma unroll
+            for (int i_ = 0; i_ < MI; ++i_) {
+                a_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rdA);
+                if ((em >> (i_ * 4)) & 1u) a_[i_] = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += NJ) {
+                uint4 b_[NJ];
+#pragma unroll
+                for (int j_ = 0; j_ < NJ; ++j_) b_[j_] = *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rdB);
+#pragma unroll
+                for (int i_ = 0; i_ < MI; ++i_)
+#pragma unroll
+                    for (int j_ = 0; j_ < NJ; ++j_) mma_step<ES>(acc[i_][jh + j_], a_[i_], b_[j_]);
+            }
+        }
+        // The B tile of step kt+1 must have landed.  Operations issued after it may stay in flight (vmcnt retires in
+        // order): with a 3-stage ring the B tile staged this step, plus a halo (4 pieces) staged this or the previous step.
+        // A halo is complete one step before its group starts (KW >= 3 with the 3-stage ring: the host guarantees it).
+        if (nbst == 3 && more) {
+            if (a_now || a_prev) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBI + 4) : "memory");
+            else                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NBI) : "memory");
+        } else if (nbst == 2 && a_now) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        a_prev = a_now;
+        __syncthreads();
+        bcur = bcur + 1 == nbst ? 0 : bcur + 1;
+        if (++kw == KWn) { kw = 0; abuf ^= 1; if (++cc == nchunk) { cc = 0; ++kh; } }
+    }
+#undef RTN_A_STAGE
+#undef RTN_B_STAGE
+
+    // ---- wave-private epilogue (rows beyond TM belong to the next tile)
+    float* S = reinterpret_cast<float*>(lds + wave * EPI_WAVE_BYTES);
+    constexpr int TPRW = WN / 8, RPPW = 64 / TPRW, NITW = 32 / RPPW;
+    const int ecol = (lane % TPRW) * 8;
+    const int n = n0 + wn * WN + ecol;
+    const bool ncol_ok = n < p.N;
+    const bool res_vec = (p.flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) && p.vec_ok;
+    float bv[8];
+    load_bias8(p, ncol_ok ? n : 0, bv);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        RowRef rows[NITW];
+        ResVec<ES> pre[NITW];
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            const int rloc = wm * 64 + hh * 32 + lane / TPRW + it * RPPW;
+            rows[it] = row_ref(p, G, m0 + rloc, M, cells, Wout);
+            rows[it].valid = rows[it].valid && ncol_ok && rloc < TM;
+            if (res_vec) res_prefetch<ES>(p, G, rows[it], Wout, ncol_ok ? n : 0, pre[it]);
+            if (p.flags & RTN_CONV_RELU_MASK) mask_prefetch<ES>(G, rows[it], ncol_ok ? n : 0, pre[it]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(i * 16 + kq * 4 + r) * SLDW + j * 16 + lrow] = acc[hh * 2 + i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int it = 0; it < NITW; ++it) {
+            const float* sp = S + (lane / TPRW + it * RPPW) * SLDW + ecol;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp);
+            const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+}
+
 // Tuning knobs, read on every call so one process can A/B them: RTN_CONV_IMPL=1|2 forces a kernel generation
 // (unset/0 = heuristic); RTN_CONV_IL=1 interleaves the staging DMA issues between MFMA groups
 // instead of issuing them ahead of the MFMA block (measured slower: 1084 vs 1226 TF/s on the head layers).
@@ -789,7 +1029,7 @@ int rtn_env_int(const char* name, int dflt) {
 }
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
-    return (v == 1 || v == 2) ? v : 0;
+    return (v >= 1 && v <= 3) ? v : 0;
 }
 
 int ilog2_exact(int v) {
@@ -869,7 +1109,20 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
             impl = (stream64 || splitk) ? 1 : 2;
         }
     }
-    const int TM = impl == 2 ? BM2 : BM;
+    // halo-sharing kernel: stride-1 'same' KHxKW conv over dense NHWC inputs whose taps span whole 128-byte chunks
+    bool halo_ok = d->KW >= 2 && d->KW <= 4 && d->sy == 1 && d->sx == 1 && (d->Crun * es) % 128 == 0 && d->pix_stride == d->Crun &&
+                   d->pad_l >= 0 && d->pad_l < d->KW && d->pad_t >= 0 && d->pad_t < d->KH;
+    for (int i = 0; i < d->ngroups && halo_ok; ++i) {
+        const rtn_conv_group_t& s = d->g[i];
+        if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
+            s.in_img_stride != (long long)s.Hin * s.in_row_stride) halo_ok = false;
+    }
+    if (impl == 3 && !halo_ok) impl = 2;
+    // measured (tools/ab_conv.py, RTN_CONV_HALO=0|1): +3..4 % on the 256-channel 3x3 layers (heads, P3, P4, res4), none or a
+    // small loss below that, so the narrower layers stay on the per-tap kernel.  RTN_CONV_HALO=2 forces it wherever it applies.
+    const int halo_env = rtn_env_int("RTN_CONV_HALO", 1);
+    if (impl == 2 && halo_ok && rtn_conv_impl_override() == 0 && (halo_env == 2 || (halo_env == 1 && d->N >= 256))) impl = 3;
+    const int TM = impl == 3 ? BM2 - (d->KW - 1) : (impl == 2 ? BM2 : BM);
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
         KGroup& g = p.g[i];
@@ -932,8 +1185,8 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     }
     (void)out_f32;
     if ((d->flags & RTN_CONV_RELU_MASK) && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv: RELU_MASK needs N, out_ld, strides multiples of 8");
-    int BN = impl == 2 ? bn2 : (d->N <= 64 ? 64 : 128);
-    if (impl == 2) {
+    int BN = impl >= 2 ? bn2 : (d->N <= 64 ? 64 : 128);
+    if (impl >= 2) {
         const int bn_env = rtn_env_int("RTN_CONV_BN2", 0);   // A/B override of the 256-row kernel's tile width
         if ((bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
     }
@@ -949,6 +1202,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     p.cshift = cshift;
     p.crun_mask = d->Crun - 1;
     p.KW = d->KW;
+    p.KH = d->KH;
     p.kw_inv = (65536 + d->KW - 1) / d->KW;
     {   // the reciprocal must reproduce kpos / KW for every tap index
         for (int kp = 0; kp < d->KH * d->KW; ++kp)
@@ -977,7 +1231,32 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     if (grid < 1 || grid > 0x7fffffffll) return rtn_fail(h, RTN_EINVAL, "conv: grid %lld", grid);
 
     dim3 gdim((unsigned)grid);
-    if (impl == 2) {
+    if (impl == 3) {
+        dim3 bdim(NT2);
+        const unsigned epib = 8u * 32u * (unsigned)(BN / 2 + 4) * 4u;
+        int nbst = 2;      // RTN_CONV_STAGES=3: a third B stage (fits beside the halos for every tile width) changed nothing measurable
+        const int nbst_env = rtn_env_int("RTN_CONV_STAGES", 0);
+        if (nbst_env == 2 || nbst_env == 3) nbst = nbst_env;
+        if (d->KW < 3) nbst = 2;
+        p.nstages = nbst;
+        unsigned ldsb = 2u * BM2 * 128u + (unsigned)nbst * (unsigned)BN * 128u;
+        if (ldsb < epib) ldsb = epib;
+        p.korder_chunks = d->Crun * es / 128;
+        p.korder_kw = d->KW;
+#define RTN_L3(E, B)                                                                                     \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm3_kernel<E, B>,                        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_igemm3_kernel<E, B>), gdim, bdim, ldsb, h->stream, p);                  \
+    } while (0)
+        if (es == 2) { if (BN == 64) RTN_L3(2, 64); else if (BN == 128) RTN_L3(2, 128); else RTN_L3(2, 256); }
+        else         { if (BN == 64) RTN_L3(4, 64); else if (BN == 128) RTN_L3(4, 128); else RTN_L3(4, 256); }
+#undef RTN_L3
+    } else if (impl == 2) {
         dim3 bdim(NT2);
         const bool il = rtn_env_int("RTN_CONV_IL", 0) != 0;
         // LDS: one stage when the K loop is a single step (the streaming 1x1 layers: more workgroups per CU), else two

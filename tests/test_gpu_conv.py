@@ -177,6 +177,30 @@ def test_conv_layers(pkg, handle, dtype, case):
     check(gots, wants, ld, n, dtype)
 
 
+GEN_CASES = [
+    # (levels, cin, cout, res, B): 3x3 stride-1 'same' layers, every kernel generation must agree with the reference
+    ([(25, 42)], 256, 256, None, 3),                       # tiles of 254/256 rows straddle image rows and image boundaries
+    ([(7, 5), (3, 2), (1, 1), (2, 1)], 128, 64, None, 2),  # grouped, widths 1 and 2: both horizontal edges on one pixel
+    ([(31, 17)], 64, 192, "same", 2),                      # one 128-byte chunk per tap, N not a tile multiple, shortcut add
+    ([(40, 67)], 256, 256, "up", 1),                       # upsampled residual; W = 67 never aligns with the tile
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, None, 2),
+]
+
+
+@pytest.mark.parametrize("impl", [1, 2, 3])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", range(len(GEN_CASES)))
+def test_conv3x3_every_kernel_generation(pkg, handle, monkeypatch, dtype, case, impl):
+    """RTN_CONV_IMPL pins the kernel generation (1: 128-row register-staged, 2: 256-row LDS-DMA per tap, 3: 256-row with
+    the kernel row's taps sharing one staged halo; the library reads the knob on every call)."""
+    levels, cin, cout, res, B = GEN_CASES[case]
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", str(impl))
+    flags = L.CONV_RELU | (L.CONV_RES_SAME if res == "same" else 0) | (L.CONV_RES_UPSAMPLE if res == "up" else 0)
+    gots, wants, ld, n = run_case(pkg, handle, dtype, levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=40 + case)
+    check(gots, wants, ld, n, dtype)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cout,sig", [(36, False), (9, True), (18, True)])
 def test_head_output_concat(pkg, handle, dtype, cout, sig):
