@@ -43,6 +43,8 @@ typedef enum { RTN_BF16 = 0, RTN_F32 = 1 } rtn_dtype_t;
 /* ---- lifetime ------------------------------------------------------------------- */
 int  rtn_create(rtn_handle_t* out, int device);
 int  rtn_destroy(rtn_handle_t h);
+/* why the last rtn_create of this process failed (which HIP call, its error string); "" after a success */
+const char* rtn_create_error(void);
 /* stream: a hipStream_t (as void*); NULL = the default stream. */
 int  rtn_set_stream(rtn_handle_t h, void* stream);
 const char* rtn_last_error(rtn_handle_t h);

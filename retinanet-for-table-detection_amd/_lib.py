@@ -63,6 +63,7 @@ _P, _I, _I64, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doubl
 SIGNATURES = {
     "rtn_create": (_I, [C.POINTER(_P), _I]),
     "rtn_destroy": (_I, [_P]),
+    "rtn_create_error": (C.c_char_p, []),
     "rtn_set_stream": (_I, [_P, _P]),
     "rtn_last_error": (C.c_char_p, [_P]),
     "rtn_version": (C.c_char_p, []),
@@ -134,7 +135,7 @@ class Handle:
         self._h = _P()
         rc = lib.rtn_create(C.byref(self._h), int(device))
         if rc != 0:
-            raise RtnError(rc, "rtn_create(device=%d) failed (no usable GPU?)" % device)
+            raise RtnError(rc, "rtn_create(device=%d) failed: %s" % (device, lib.rtn_create_error().decode() or "no usable GPU?"))
         self.device = device
 
     @property

@@ -4,21 +4,30 @@
 
 extern "C" const char* rtn_version(void) { return "librtn 0.1 (gfx950)"; }
 
+static char g_create_err[256] = "";
+extern "C" const char* rtn_create_error(void) { return g_create_err; }
+
 extern "C" int rtn_create(rtn_handle_t* out, int device) {
     if (!out) return RTN_EINVAL;
     *out = nullptr;
+    g_create_err[0] = 0;
     rtn_ctx* h = new (std::nothrow) rtn_ctx();
     if (!h) return RTN_ENOMEM;
     memset(h, 0, sizeof(*h));
     h->device = device;
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(&h->zero_page, 256);
-    if (e == hipSuccess) e = hipMemset(h->zero_page, 0, 256);
     h->splitk_bytes = 64u << 20;
-    if (e == hipSuccess) e = hipMalloc((void**)&h->scratch[0].ptr, h->splitk_bytes);
     hipDeviceProp_t prop;
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    const char* what = "hipSetDevice";
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) { what = "hipMalloc(zero page)"; e = hipMalloc(&h->zero_page, 256); }
+    if (e == hipSuccess) { what = "hipMemset(zero page)"; e = hipMemset(h->zero_page, 0, 256); }
+    if (e == hipSuccess) { what = "hipMalloc(split-K scratch)"; e = hipMalloc((void**)&h->scratch[0].ptr, h->splitk_bytes); }
+    if (e == hipSuccess) { what = "hipGetDeviceProperties"; e = hipGetDeviceProperties(&prop, device); }
     if (e != hipSuccess) {
+        snprintf(g_create_err, sizeof(g_create_err), "%s on device %d: %s", what, device, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (h->zero_page) (void)hipFree(h->zero_page);
+        if (h->scratch[0].ptr) (void)hipFree(h->scratch[0].ptr);
         delete h;
         return RTN_EHIP;
     }
