@@ -243,24 +243,31 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: events around every conv launch of extra (untimed) steps
         plan = eng._plan(BATCH, CANVAS[0], CANVAS[1])
-        conv_ops = [op for op in plan["ops"] if op[0] == "conv"]
-        flops_step = sum(conv_flops(op[1], BATCH) for op in conv_ops)
+        active = eng.active_ops(plan)
+        conv_ops = [op for op in active if op[0] == "conv"]
+        fused_stem = any(op[0] == "stem" for op in active)          # conv1 + ReLU + pool1 in one kernel: its MFMA work is conv1's
+        stem_conv = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "conv1"][0]
+        flops_step = sum(conv_flops(op[1], BATCH) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         reps = 3
         per_op_ms = eng.profile_ops(x, reps=reps)
-        conv_ms = sum(ms for kind, ms in per_op_ms if kind == "conv") / reps
-        other_ms = sum(ms for kind, ms in per_op_ms if kind != "conv") / reps
+        conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem")) / reps
+        other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem")) / reps
         achieved = flops_step / (conv_ms * 1e-3) / 1e12
         ncand = int((plan["classification"] > 0.05).sum().item())
         bytes_step = sum(conv_bytes(op[1], BATCH) for op in conv_ops)
+        n_launch = len(conv_ops) + (1 if fused_stem else 0)
+        if fused_stem:                                                 # image in (bf16, 3 ch), pooled tensor out, filters
+            H1, W1 = (CANVAS[0] - 1) // 2 + 1, (CANVAS[1] - 1) // 2 + 1
+            bytes_step += BATCH * (CANVAS[0] * CANVAS[1] * 3 * 2 + ((H1 + 1) // 2) * ((W1 + 1) // 2) * 64 * 2) + 64 * 256 * 2
         pmc = pmc_traffic()
         roofline = {"bound": "mfma", "kernel": "conv_igemm2_kernel/conv_igemm_kernel<bf16> (all conv launches of a step)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
                     "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None),
                     "traffic_source": ("profiles/r1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if pmc else None),
-                    "algorithmic_bytes_per_launch": bytes_step / len(conv_ops),
-                    "launches_per_step": len(conv_ops), "avg_launch_ms": conv_ms / len(conv_ops),
-                    "flop_per_step": flops_step, "flop_per_launch": flops_step / len(conv_ops),
+                    "algorithmic_bytes_per_launch": bytes_step / n_launch,
+                    "launches_per_step": n_launch, "avg_launch_ms": conv_ms / n_launch,
+                    "flop_per_step": flops_step, "flop_per_launch": flops_step / n_launch,
                     "conv_ms_per_step": conv_ms, "non_conv_ms_per_step": other_ms}
         out = {"metric": "images/sec RetinaNet R50-FPN 800x1333 inference", "value": value, "unit": "images/sec",
                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

@@ -190,6 +190,16 @@ int rtn_adam_clipnorm_step(rtn_handle_t h, float* w, float* m, float* v, const f
 int rtn_stem_pack(rtn_handle_t h, const void* src, int src_dtype, void* dst, int dst_dtype,
                   int B, int H, int W, int Hp, int Wp);
 
+/* ---- conv1 + ReLU + pool1 in one kernel (inference, bf16 path) -------------------------
+ * ZeroPadding2D(3) + conv1 7x7/2 (frozen BN folded into w / bias) + ReLU + MaxPool 3x3/2 'same' of keras_resnet
+ * (model/defineModel.py:357-389 builds it) on the packed image rtn_stem_pack writes ([B][Hp][Wp][4] bf16).
+ * w_packed: the packed stem filters [w_rows >= 64][8 kernel rows][32] bf16 (kernel row kh = 7 pixels x 4 channels + 4 zero
+ * elements, row 7 all zero) as rtn_conv2d_fwd takes them; out: [B][H2][W2][64] bf16, H1 = (H-1)/2+1, H2 = (H1+1)/2 (W alike).
+ * Bit-identical to rtn_conv2d_fwd (RELU) -> rtn_maxpool3x3s2_tfsame_fwd on the same packed image: one MFMA per kernel row in
+ * the same order, one bf16 rounding of the ReLU output; the 34 MB/image conv1 tensor never reaches HBM. */
+int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
+                       const float* bias, void* out, int B, int H, int W);
+
 /* ---- MaxPool 3x3 / 2, TF 'same' (keras_resnet pool1; -inf padding) ----------------- */
 int rtn_maxpool3x3s2_tfsame_fwd(rtn_handle_t h, const void* in, void* out, int dtype,
                                 int B, int Hin, int Win, int C);

@@ -1084,8 +1084,9 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
         //    rounds of CUs) x (time of one tile); one 256x{64,128,256} tile costs 1 : 2.02 : 3.44 on a long K loop.
         //    Wide tiles therefore only pay when the grid stays many rounds deep (the head towers);
         //  * on short K loops the epilogue and HBM dominate and the narrow tile (more workgroups in flight) wins;
-        //  * the 128-row register-staged kernel (3 workgroups/CU) keeps the <=64-channel layers that are pure
-        //    streaming: 1x1 with K >= 256 (res2*_branch2a) and the grouped head outputs.
+        //  * the 128-row register-staged kernel (3 workgroups/CU) keeps the <=64-channel 1x1 layers with K >= 256
+        //    (res2*_branch2a: pure streaming, 0.074 vs 0.080 ms); the grouped head outputs moved to the 256-row kernel
+        //    once it had dynamic LDS (0.113 -> 0.087 ms).
         const long long mt2 = (Mtot + BM2 - 1) / BM2;
         const int cus = h->num_cus > 0 ? h->num_cus : 256;
         if (Ktot * es >= 2048 && d->N > 64) {
@@ -1102,7 +1103,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
             bn2 = 64;
         }
         if (impl == 0) {
-            const bool stream64 = d->N <= 64 && ((d->KH * d->KW == 1 && Ktot * es >= 512) || d->ngroups > 1);
+            const bool stream64 = d->N <= 64 && d->KH * d->KW == 1 && Ktot * es >= 512;
             // tiny-M, long-K layers (P6, P7): only the 128-row kernel has the split-K path
             const long long grid1 = ((Mtot + BM - 1) / BM) * ((d->N + 127) / 128);
             const bool splitk = d->ngroups == 1 && grid1 < 128 && Ktot * es / 128 >= 16;

@@ -83,7 +83,8 @@ class Engine:
         self.plans = {}
         self.state = None
         self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
-        self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # head towers on two HIP streams
+        self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
+        self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
         self._side = None
 
     # ------------------------------------------------------------------ weights
@@ -204,6 +205,9 @@ class Engine:
         pool_idx = torch.empty(B * H2 * W2 * 64, dtype=torch.uint8, device=dev)     # winning taps (training mode only)
         keep.append(pool_idx)
         ops.append(("pool", c1, x, (B, H1, W1, 64), pool_idx))
+        # inference, bf16: the three stem ops above collapse into one kernel (rtn_stem_conv_pool)
+        stem_fused = ("stem", x, (B, H, W), wk, bk, xp, (Hp, Wp))
+        n_stem_ops = len(ops)
         # ---- bottleneck stages
         feats = []
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
@@ -279,7 +283,9 @@ class Engine:
             tower_ranges.append((tower_start, len(ops)))
         ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
         sched = self._schedule(ops)
-        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        fused_ops = [ops[0], stem_fused] + ops[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
+        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep,
+                "fused_ops": fused_ops, "fused_sched": self._schedule(fused_ops), "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -299,6 +305,8 @@ class Engine:
             return reads, [t.data_ptr() for t in m["ys"]]
         if kind == "pack":
             return [], [op[1].data_ptr()]
+        if kind == "stem":
+            return [op[5].data_ptr()], [op[1].data_ptr()]
         if kind == "pool":
             return [op[1].data_ptr()], [op[2].data_ptr(), op[4].data_ptr()]
         if kind == "relu":
@@ -373,18 +381,19 @@ class Engine:
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)
         self._bind_stream()
-        ops = plan["ops"]
+        fused = self._fused()
+        ops = plan["fused_ops"] if fused else plan["ops"]
         if not self.two_streams:
             for op in ops:
                 self._run_op(op, images)
             return plan["regression"], plan["classification"]
-        sched = plan["sched"]
+        sched = plan["fused_sched"] if fused else plan["sched"]
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         streams = [main] + self._side
         lanes, waits = sched["lanes"], sched["waits"]
-        events = plan.setdefault("events", {i: torch.cuda.Event() for i in sched["events"]})
+        events = plan.setdefault("fused_events" if fused else "events", {i: torch.cuda.Event() for i in sched["events"]})
         fork = plan.setdefault("fork", torch.cuda.Event())
         fork.record(main)                                    # side lanes start after everything queued before this pass
         for st in streams[1:sched["nlanes"]]:
@@ -405,11 +414,22 @@ class Engine:
         self.h.set_stream(main.cuda_stream)
         return plan["regression"], plan["classification"]
 
+    def _fused(self):
+        return self.fuse_stem and not self.training and self.dtype == "bf16"
+
+    def active_ops(self, plan):
+        """The op list forward() executes: the training / fp32 paths keep pack, conv1, pool1 as separate launches."""
+        return plan["fused_ops"] if self._fused() else plan["ops"]
+
     def _run_op(self, op, images):
         lib, h = L.lib, self.h
         kind = op[0]
         if kind == "conv":
             h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
+        elif kind == "stem":
+            Bn, Hn, Wn = op[2]
+            h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
+                                           op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn))
         elif kind == "pack":
             xi = op[2]
             h.check(lib.rtn_stem_pack(h.raw, images.data_ptr(), _SRC_DT[images.dtype], op[1].data_ptr(), self.rdt,
@@ -432,7 +452,7 @@ class Engine:
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)
         self._bind_stream()
-        ops = plan["ops"]
+        ops = self.active_ops(plan)
         totals = [0.0] * (len(ops) + 1)
         for _ in range(reps):
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 2)]

@@ -152,3 +152,39 @@ def test_stream_lanes_give_the_single_stream_bits(pkg, state, dtype, B, hw):
         r1, c1 = eng.forward(x)
         torch.cuda.synchronize()
         assert torch.equal(r0, r1) and torch.equal(c0, c1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,src", [((64, 96), "bf16"), ((67, 101), "f32"), ((33, 35), "u8"), ((130, 71), "bf16")])
+def test_fused_stem_matches_the_three_kernel_stem(pkg, state, hw, src):
+    """rtn_stem_conv_pool (conv1 + ReLU + pool1 in one kernel, inference bf16 path) against the same engine running
+    rtn_stem_pack -> rtn_conv2d_fwd -> rtn_maxpool3x3s2_tfsame_fwd.  Both multiply bf16 inputs and weights and round the ReLU
+    output to bf16 once; only the f32 summation order differs, so outputs agree to one bf16 ulp of the activation scale
+    (stated: 2^-7 relative to the largest activation; most elements are identical).  Odd sizes exercise both pool paddings
+    (H1 even: pad 0/1, H1 odd: pad 1/1), partial tiles and the image border inside a tile."""
+    E, _ = mods(pkg)
+    B = 2
+    g = torch.Generator().manual_seed(11)
+    if src == "u8":
+        x = torch.randint(0, 256, (B, hw[0], hw[1], 3), generator=g, dtype=torch.uint8).cuda()
+    else:
+        x = (torch.rand(B, hw[0], hw[1], 3, generator=g) * 2 - 1).to({"bf16": torch.bfloat16, "f32": torch.float32}[src]).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.load_state(state)
+    outs = {}
+    for fuse in (False, True):
+        eng.fuse_stem = fuse
+        [op for op in eng._plan(B, hw[0], hw[1])["ops"] if op[0] == "pool"][0][2].fill_(-3.0)     # both paths write this buffer
+        eng.forward(x)
+        torch.cuda.synchronize()
+        plan = eng._plan(B, hw[0], hw[1])
+        pool_out = [op for op in plan["ops"] if op[0] == "pool"][0][2]
+        outs[fuse] = pool_out.float().cpu().clone()
+        assert any(op[0] == "stem" for op in eng.active_ops(plan)) == fuse
+    a, b = outs[False], outs[True]
+    scale = float(a.abs().max())
+    assert scale > 0.1
+    err = float((a - b).abs().max())
+    same = float((a == b).float().mean())
+    print("fused stem: max |diff| %.3e (scale %.2f), identical elements %.4f" % (err, scale, same))
+    assert err <= scale * 2.0 ** -7 and same > 0.9

@@ -18,7 +18,7 @@ per = eng.profile_ops(x, reps=reps)
 plan = eng._plan(B, *bench.CANVAS)
 tot = 0.0
 print("%-28s %9s %9s %8s  shape" % ("op", "ms", "GFLOP", "TFLOP/s"))
-for (kind, ms), op in zip(per, plan["ops"] + [("detect",)]):
+for (kind, ms), op in zip(per, eng.active_ops(plan) + [("detect",)]):
     ms /= reps; tot += ms
     if kind == "conv":
         d = op[1]; fl = bench.conv_flops(d, B)
