@@ -802,10 +802,14 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     const int ntn = (d->N + CH - 1) / CH;
     p.ntiles_k = (int)((Ktot + CH - 1) / CH);
     const long long out_tiles = (long long)ntn * p.ntiles_k;
-    // target workgroup count (RTN_WGRAD_BLOCKS overrides): measured on the head layers 512 -> 0.57 ms, 1024 -> 0.39 ms
-    long long target = 1024;
+    // Workgroup count: whole rounds of the resident slots (two 256-thread workgroups per CU), rounded DOWN - 1044 workgroups
+    // on 1024 slots cost a third round (training step 40.8 -> 38.8 ms).  RTN_WGRAD_BLOCKS overrides the target.
+    // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
+    // bound by the latency of its register-staged loads, not by MFMA work per byte.)
+    const long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * 2;
+    long long target = slots * 2;
     if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
-    long long nsplit = (target + out_tiles - 1) / out_tiles;
+    long long nsplit = target / out_tiles;
     if (nsplit > tiles) nsplit = tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;
