@@ -52,6 +52,7 @@ struct WParams {
     int db_n;            // valid bias entries
     const uint4* rowinfo;
     int ngroups, total_tiles, tiles_per_split, ntiles_k;
+    int out_tiles, xcd_map;   // xcd_map: 1-D grid, the output tiles of one pixel split share an XCD (its L2)
     int N, Ktot;
     int cshift, crun_mask, kw_inv, KW;
     int pix_stride_b, sy, sx, pad_t, pad_l, dy_ld_b;
@@ -83,6 +84,64 @@ __global__ __launch_bounds__(256) void wgrad_rowinfo_kernel(const WParams p, uin
     }
 }
 
+// One 64-pixel step of the MFMA loop: transposed fragment reads of the dY tile (A) and the X tile (B) of one LDS buffer.
+template <int ES, int FI, int WT>
+__device__ __forceinline__ void wgrad_step(const char* A, const char* B, int lane, int wm, int wn, f32x4 (&acc)[FI][FI]) {
+    if constexpr (ES == 2) {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int swz = (g & 1) << 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = 32 * s + 8 * g + q;
+            s16x8 af[FI], bf[FI];
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int ca = (wm * WT + 16 * i + 4 * pp) * 2;       // byte column inside the 256-byte row
+                const int aoff = row * WG_ROWB + ((((ca >> 4) ^ swz)) << 4) + (ca & 15);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WG_ROWB));
+                af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int cb = (wn * WT + 16 * i + 4 * pp) * 2;
+                const int boff = row * WG_ROWB + ((((cb >> 4) ^ swz)) << 4) + (cb & 15);
+                const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
+                const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WG_ROWB));
+                bf[i] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                        __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        }
+    } else {
+        const int li = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int row = 4 * s + kq;
+            const int swz = ((row >> 3) & 1) << 3;
+            float af[FI], bf[FI];
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int ca = (wm * WT + 16 * i + li) * 4;
+                af[i] = *reinterpret_cast<const float*>(A + row * WG_ROWB + (((ca >> 4) ^ swz) << 4) + (ca & 15));
+                const int cb = (wn * WT + 16 * i + li) * 4;
+                bf[i] = *reinterpret_cast<const float*>(B + row * WG_ROWB + (((cb >> 4) ^ swz) << 4) + (cb & 15));
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// Loads run TWO pixel tiles ahead of the MFMAs (two register sets: the tile staged into LDS at the end of a step was
+// requested a whole step earlier).  Workgroups that read the same pixel range (all output tiles of one split) are placed
+// on one XCD (p.xcd_map) so they share its L2.  Knob-ablated on the batch-16 training step (wgrad ~13.5 ms of 38.7):
+// operand loads ~5-9 ms, MFMA + transposed reads ~0.7-4 ms (hidden behind the loads), float atomics 1.9 ms - every one of the
+// (N/128)*(K/128) output tiles re-reads all pixels (6.4 GB of L2->LDS traffic per head layer at 65 FLOP/B), which is what
+// bounds this kernel.
 template <int ES>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
     constexpr int CE = 16 / ES;                // elements per 16-byte chunk
@@ -91,10 +150,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
     constexpr int FI = WT / 16;                // 16x16 MFMA tiles per wave side: 4 / 2
     __shared__ __attribute__((aligned(16))) char lds[4 * WG_TILE_B];   // [buf][dY | X]
 
-    const int tile_n = blockIdx.x / p.ntiles_k;
-    const int tile_k = blockIdx.x - tile_n * p.ntiles_k;
+    int otile, split;
+    if (p.xcd_map) {                           // 1-D grid; gridDim.x = out_tiles * nsplit, nsplit a multiple of 8
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int sl = j / p.out_tiles;
+        otile = j - sl * p.out_tiles;
+        split = sl * 8 + xcd;
+    } else {
+        otile = blockIdx.x;
+        split = blockIdx.y;
+    }
+    const int tile_n = otile / p.ntiles_k;
+    const int tile_k = otile - tile_n * p.ntiles_k;
     const int n0 = tile_n * CH, k0 = tile_k * CH;
-    const int tlo = blockIdx.y * p.tiles_per_split;
+    const int tlo = split * p.tiles_per_split;
     int thi = tlo + p.tiles_per_split;
     thi = thi < p.total_tiles ? thi : p.total_tiles;
     if (tlo >= thi) return;
@@ -125,14 +194,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
     float bsum[CE];
 #pragma unroll
     for (int j = 0; j < CE; ++j) bsum[j] = 0.f;
-    uint4 ra[4], rb[4];
-    uint4 ri[4];                                  // row info of the NEXT tile to load (prefetched one tile ahead)
+    uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+    uint4 ri[4];                                  // row info of the NEXT tile to load (prefetched one load ahead)
 #define WG_ROWINFO(TILE)                                                                                            \
     {                                                                                                               \
         const int tt_ = (TILE) < thi ? (TILE) : thi - 1;                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ri[i_] = p.rowinfo[(long long)tt_ * 64 + r0 + 16 * i_];    \
     }
-#define WG_LOAD(TILE)                                                                                               \
+#define WG_LOAD(TILE, RA, RB)                                                                                       \
     {                                                                                                               \
         int gi_ = 0;                                                                                                \
         _Pragma("unroll") for (int i_ = 1; i_ < RTN_MAX_GROUPS; ++i_)                                               \
@@ -147,16 +216,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
             const int iy_ = (int)(short)(ri[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri[i_].z >> 16) + kw;         \
             const bool ok_ = kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;            \
-            rb[i_] = buffer_load16(xs_, ok_ ? ri[i_].x + delta_ : OOB_OFFSET);                                      \
-            ra[i_] = buffer_load16(ys_, (nvalid && ri[i_].y != OOB_OFFSET) ? ri[i_].y + dyo : OOB_OFFSET);          \
+            RB[i_] = buffer_load16(xs_, ok_ ? ri[i_].x + delta_ : OOB_OFFSET);                                      \
+            RA[i_] = buffer_load16(ys_, (nvalid && ri[i_].y != OOB_OFFSET) ? ri[i_].y + dyo : OOB_OFFSET);          \
         }                                                                                                           \
         WG_ROWINFO((TILE) + 1);                                                                                     \
     }
-#define WG_STORE(BUF)                                                                                               \
+#define WG_STORE(BUF, RA, RB)                                                                                       \
     {                                                                                                               \
         if (do_bias) {                                                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
-                const unsigned w4_[4] = {ra[i_].x, ra[i_].y, ra[i_].z, ra[i_].w};                                   \
+                const unsigned w4_[4] = {RA[i_].x, RA[i_].y, RA[i_].z, RA[i_].w};                                   \
                 if constexpr (ES == 2) {                                                                            \
                     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                              \
                         bsum[2 * j_] += __uint_as_float(w4_[j_] << 16);                                             \
@@ -169,70 +238,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
         }                                                                                                           \
         char* A_ = lds + (BUF) * 2 * WG_TILE_B;                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
-            *reinterpret_cast<uint4*>(A_ + st_off + i_ * 16 * WG_ROWB) = ra[i_];                                    \
-            *reinterpret_cast<uint4*>(A_ + WG_TILE_B + st_off + i_ * 16 * WG_ROWB) = rb[i_];                        \
+            *reinterpret_cast<uint4*>(A_ + st_off + i_ * 16 * WG_ROWB) = RA[i_];                                    \
+            *reinterpret_cast<uint4*>(A_ + WG_TILE_B + st_off + i_ * 16 * WG_ROWB) = RB[i_];                        \
         }                                                                                                           \
     }
 
     WG_ROWINFO(tlo);
-    WG_LOAD(tlo);
-    WG_STORE(0);
+    WG_LOAD(tlo, ra0, rb0);
+    WG_STORE(0, ra0, rb0);
+    if (tlo + 1 < thi) WG_LOAD(tlo + 1, ra1, rb1);
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int tile = tlo; tile < thi; ++tile) {
-        const bool more = tile + 1 < thi;
-        if (more) WG_LOAD(tile + 1);
-        const char* A = lds + cur * 2 * WG_TILE_B;     // dY tile
-        const char* B = A + WG_TILE_B;                 // X tile
-        if constexpr (ES == 2) {
-            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-            const int swz = (g & 1) << 3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int row = 32 * s + 8 * g + q;
-                s16x8 af[FI], bf[FI];
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    const int ca = (wm * WT + 16 * i + 4 * pp) * 2;       // byte column inside the 256-byte row
-                    const int aoff = row * WG_ROWB + ((((ca >> 4) ^ swz)) << 4) + (ca & 15);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WG_ROWB));
-                    af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const int cb = (wn * WT + 16 * i + 4 * pp) * 2;
-                    const int boff = row * WG_ROWB + ((((cb >> 4) ^ swz)) << 4) + (cb & 15);
-                    const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
-                    const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WG_ROWB));
-                    bf[i] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
-                }
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                            __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-            }
-        } else {
-            const int li = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const int row = 4 * s + kq;
-                const int swz = ((row >> 3) & 1) << 3;
-                float af[FI], bf[FI];
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    const int ca = (wm * WT + 16 * i + li) * 4;
-                    af[i] = *reinterpret_cast<const float*>(A + row * WG_ROWB + (((ca >> 4) ^ swz) << 4) + (ca & 15));
-                    const int cb = (wn * WT + 16 * i + li) * 4;
-                    bf[i] = *reinterpret_cast<const float*>(B + row * WG_ROWB + (((cb >> 4) ^ swz) << 4) + (cb & 15));
-                }
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (more) WG_STORE(cur ^ 1);
+    for (int tile = tlo; tile < thi; tile += 2) {
+        // LDS[cur] = tile, set 1 = tile+1 (requested a step ago); request tile+2 into set 0
+        if (tile + 2 < thi) WG_LOAD(tile + 2, ra0, rb0);
+        wgrad_step<ES, FI, WT>(lds + cur * 2 * WG_TILE_B, lds + cur * 2 * WG_TILE_B + WG_TILE_B, lane, wm, wn, acc);
+        if (tile + 1 < thi) WG_STORE(cur ^ 1, ra1, rb1);
+        __syncthreads();
+        cur ^= 1;
+        if (tile + 1 >= thi) break;
+        // LDS[cur] = tile+1, set 0 = tile+2; request tile+3 into set 1
+        if (tile + 3 < thi) WG_LOAD(tile + 3, ra1, rb1);
+        wgrad_step<ES, FI, WT>(lds + cur * 2 * WG_TILE_B, lds + cur * 2 * WG_TILE_B + WG_TILE_B, lane, wm, wn, acc);
+        if (tile + 2 < thi) WG_STORE(cur ^ 1, ra0, rb0);
         __syncthreads();
         cur ^= 1;
     }
@@ -813,13 +842,21 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     if (nsplit > tiles) nsplit = tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;
+    bool xcd_map = nsplit >= 8 && getenv("RTN_WGRAD_XCD") == nullptr;
+    if (xcd_map) nsplit &= ~7ll;
     p.tiles_per_split = (int)((tiles + nsplit - 1) / nsplit);
     nsplit = (tiles + p.tiles_per_split - 1) / p.tiles_per_split;
 
     if (es == 2) hipLaunchKernelGGL((wgrad_rowinfo_kernel<2>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
     else         hipLaunchKernelGGL((wgrad_rowinfo_kernel<4>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
     RTN_CHECK_LAUNCH(h, "wgrad_rowinfo_kernel");
-    dim3 grid((unsigned)out_tiles, (unsigned)nsplit);
+    if (xcd_map && (nsplit & 7)) {              // the recomputed split count must stay a multiple of 8 for the XCD map
+        const long long up = (nsplit + 7) & ~7ll;    // extra splits are empty (tlo >= thi) and return at once
+        nsplit = up;
+    }
+    p.out_tiles = (int)out_tiles;
+    p.xcd_map = xcd_map ? 1 : 0;
+    dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
     if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else         hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
