@@ -196,8 +196,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # One rank per GPU over RCCL ("nccl" on ROCm).  Rehearsal on a one-GPU box: RTN_BENCH_SHARE_GPU=1 puts every rank on
+        # device 0 and RTN_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+        if os.environ.get("RTN_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
+        backend = os.environ.get("RTN_DIST_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
