@@ -252,17 +252,20 @@ def main():
         # ---- roofline of the dominant kernel: events around every conv launch of extra (untimed) steps
         plan = eng._plan(BATCH, CANVAS[0], CANVAS[1])
         active = eng.active_ops(plan)
-        conv_ops = [op for op in active if op[0] == "conv"]
+        conv_ops = [op for op in active if op[0] in ("conv", "dual")]
         fused_stem = any(op[0] == "stem" for op in active)          # conv1 + ReLU + pool1 in one kernel: its MFMA work is conv1's
         stem_conv = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "conv1"][0]
-        flops_step = sum(conv_flops(op[1], BATCH) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
+        # a "dual" launch is branch2c with the projection shortcut appended along K: the same FLOPs as the two layers it replaces
+        flops_step = sum(conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
+                         for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         reps = 3
         per_op_ms = eng.profile_ops(x, reps=reps)
-        conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem")) / reps
-        other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem")) / reps
+        conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem", "dual")) / reps
+        other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem", "dual")) / reps
         achieved = flops_step / (conv_ms * 1e-3) / 1e12
         ncand = int((plan["classification"] > 0.05).sum().item())
-        bytes_step = sum(conv_bytes(op[1], BATCH) for op in conv_ops)
+        bytes_step = sum(conv_bytes(op[1], BATCH) + ((BATCH * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
+                         for op in conv_ops)
         n_launch = len(conv_ops) + (1 if fused_stem else 0)
         if fused_stem:                                                 # image in (bf16, 3 ch), pooled tensor out, filters
             H1, W1 = (CANVAS[0] - 1) // 2 + 1, (CANVAS[1] - 1) // 2 + 1

@@ -130,6 +130,24 @@ typedef struct {
 
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
 
+/* Two 1x1 convolutions that are ADDED, as one GEMM over the concatenated K: out = W1 . in + W2 . in2[stepped] + bias (+ the
+ * epilogue of `d`).  This is the first bottleneck block of a ResNet stage (keras_resnet: res*a_branch2c + res*a_branch1,
+ * joined by keras Add; model/defineModel.py:357-389 builds the backbone): the projection shortcut never becomes a tensor.
+ * `d`: one group, KH = KW = 1, stride 1, no padding, Crun = channels of `in`; w = [w_rows][Crun + C] with the second
+ * layer's filters behind the first's along K, bias = the sum of the two biases.  `s2`: the block input, sampled at pixel
+ * (oy*step, ox*step) (step 2 = the stride-2 'valid' 1x1 shortcut of stages 3-5). */
+typedef struct {
+    const void* in;          /* NHWC, same dtype as d->dtype                          */
+    int64_t in_elems;
+    int64_t in_img_stride;   /* elements                                               */
+    int32_t in_row_stride;   /* elements                                               */
+    int32_t pix_stride;      /* elements between horizontally adjacent pixels          */
+    int32_t Hin, Win;
+    int32_t C;               /* channels read per pixel (C * sizeof multiple of 128 B) */
+    int32_t step;            /* 1 or the shortcut's stride                             */
+} rtn_conv_src2_t;
+int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2);
+
 /* Data gradient (what TF autodiff emits as Conv2DBackpropInput under fit_generator, RetinaNet.py:280).  The same
  * implicit GEMM run on dY: `in` = dY, `w` = the forward weights re-packed by rtn_pack_dgrad_weights
  * (w_d[c][(KH-1-kh, KW-1-kw, n)] = w[n][(kh,kw,c)]), pad = K-1-pad_fwd, stride 1 (a stride-2 1x1 forward conv uses

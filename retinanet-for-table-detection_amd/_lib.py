@@ -48,6 +48,14 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvSrc2(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("in_elems", C.c_int64), ("in_img_stride", C.c_int64),
+        ("in_row_stride", C.c_int32), ("pix_stride", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("C", C.c_int32), ("step", C.c_int32),
+    ]
+
+
 class AnchorCfg(C.Structure):
     _fields_ = [
         ("nlevels", C.c_int32), ("A", C.c_int32),
@@ -68,6 +76,7 @@ SIGNATURES = {
     "rtn_last_error": (C.c_char_p, [_P]),
     "rtn_version": (C.c_char_p, []),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
+    "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_conv2d_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),

@@ -109,6 +109,12 @@ struct KParams {
     int dense_out;   // out/res/mask are plain [M][ld] matrices: the epilogue needs no (image, pixel) split
     int dense_in;    // 1x1, stride 1, no padding on a contiguous NHWC input: row m starts at m * pix_stride
     int nstages;     // 256-row kernel: depth of the LDS staging ring (1..4), sized by the launcher
+    // second input of a K-concatenated 1x1 layer (rtn_conv1x1_dual_fwd): K steps >= nkt1 read `in2` (group 0 only)
+    const char* in2;
+    unsigned in2_bytes;
+    int nkt1;
+    long long in2_img_stride_b;
+    int in2_row_stride_b, in2_pix_stride_b, in2_step;
     int korder_chunks, korder_kw;   // 256-row kernel: K-step visiting order (see KOrder in the kernel); {nkt, 1} = in order
 };
 
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const KParams p
 constexpr int BM2 = 256;
 constexpr int NT2 = 512;
 
-template <int ES, int BN, bool IL>
+template <int ES, int BN, bool IL, bool DUAL = false>
 __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
     constexpr int ESH = (ES == 2) ? 1 : 2;
     constexpr int WN = BN / 2;
@@ -622,6 +628,25 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
             rowbase[i] = 0;
         }
     }
+    // second source (DUAL): pixel (b, oy*step, ox*step) of `in2`, channels walked by the K steps past nkt1
+    unsigned rowbase2[DUAL ? 4 : 1];
+    i32x4 in2_srd = in_srd;
+    if constexpr (DUAL) {
+        in2_srd = make_srd(p.in2, p.in2_bytes);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (i * 8 + wave) * 8 + lr;
+            rowbase2[i] = 0;
+            if (m < M) {
+                const int b = m / cells;
+                const int rem = m - b * cells;
+                const int oy = rem / Wout;
+                const int ox = rem - oy * Wout;
+                rowbase2[i] = (unsigned)((long long)b * p.in2_img_stride_b + (long long)oy * p.in2_step * p.in2_row_stride_b +
+                                         (long long)ox * p.in2_step * p.in2_pix_stride_b);
+            }
+        }
+    }
     // B rows beyond w_rows fall outside the weight descriptor and read as zeros
     const unsigned wbase = (unsigned)(n0 + wave * 8 + lr) * (unsigned)p.Kbytes + (unsigned)c * 16u;
     const unsigned wstep = 64u * (unsigned)p.Kbytes;
@@ -629,6 +654,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 
     // One staging piece (1 KiB per wave): D < 4 -> A row-block D of this wave, else B row-block D-4.
 #define RTN_TAPS(KT)                                                                                                \
+    const bool src2_ = DUAL && (KT) >= p.nkt1;                                                                      \
+    const unsigned delta2_ = (unsigned)(((KT) - p.nkt1) * 128 + c * 16);                                            \
     const int kb_ = (KT) * 128 + c * 16;   /* KT = position of the step in K (see KOrder) */                        \
     const int k0_ = kb_ >> ESH;                                                                                     \
     const int kpos_ = k0_ >> p.cshift;                                                                              \
@@ -642,6 +669,10 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
         if ((D) < 4) {                                                                                              \
             const int iy_ = iy0[(D) & 3] + kh_, ix_ = ix0[(D) & 3] + kw_;                                           \
             const bool ok_ = (unsigned)iy_ < (unsigned)Hin && (unsigned)ix_ < (unsigned)Win;                        \
+            if (DUAL && src2_)                                                                                      \
+                dma16_to_lds(in2_srd, iy0[(D) & 3] > -(1 << 27) ? rowbase2[DUAL ? ((D) & 3) : 0] + delta2_ : OOB_OFFSET,    \
+                             lds_base + (unsigned)((BUF) * SB + wave * 1024 + ((D) & 3) * 8192));                   \
+            else                                                                                                    \
             dma16_to_lds(in_srd, ok_ ? rowbase[(D) & 3] + delta_ : OOB_OFFSET,                                      \
                          lds_base + (unsigned)((BUF) * SB + wave * 1024 + ((D) & 3) * 8192));                       \
         } else {                                                                                                    \
@@ -1041,7 +1072,7 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
+static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr) {
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
@@ -1052,7 +1083,24 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
         return rtn_fail(h, RTN_EINVAL, "conv: non-positive dimension");
     const int cshift = ilog2_exact(d->Crun);
     if (cshift < 0 || (d->Crun * es) % 16) return rtn_fail(h, RTN_EINVAL, "conv: Crun %d must be a power of two spanning whole 16-byte chunks", d->Crun);
-    const long long Ktot = (long long)d->KH * d->KW * d->Crun;
+    long long Ktot = (long long)d->KH * d->KW * d->Crun;
+    const long long K1 = Ktot;
+    if (s2) {       // K-concatenated second source: both are 1x1 taps, the second one possibly strided
+        if (d->KH != 1 || d->KW != 1 || d->sy != 1 || d->sx != 1 || d->pad_t != 0 || d->pad_l != 0 || d->ngroups != 1)
+            return rtn_fail(h, RTN_EINVAL, "conv dual: the first source must be a single-group 1x1 stride-1 layer");
+        if (!s2->in || ((uintptr_t)s2->in & 15)) return rtn_fail(h, RTN_EINVAL, "conv dual: null / misaligned second source");
+        if (s2->C < 1 || (s2->C * es) % 128 || (K1 * es) % 128) return rtn_fail(h, RTN_EINVAL, "conv dual: both channel counts must span whole 128-byte chunks");
+        if (s2->step < 1 || s2->Hin < 1 || s2->Win < 1 || (s2->in_img_stride * es) % 16 || ((long long)s2->in_row_stride * es) % 16 || ((long long)s2->pix_stride * es) % 16)
+            return rtn_fail(h, RTN_EINVAL, "conv dual: bad second-source geometry");
+        const rtn_conv_group_t& g0 = d->g[0];
+        if ((long long)(g0.Hout - 1) * s2->step >= s2->Hin || (long long)(g0.Wout - 1) * s2->step >= s2->Win)
+            return rtn_fail(h, RTN_EBOUNDS, "conv dual: output %dx%d at step %d leaves the %dx%d second source", g0.Hout, g0.Wout, s2->step, s2->Hin, s2->Win);
+        const long long in2_max = (long long)(d->batch - 1) * s2->in_img_stride + (long long)(g0.Hout - 1) * s2->step * s2->in_row_stride +
+                                  (long long)(g0.Wout - 1) * s2->step * s2->pix_stride + s2->C;
+        if (in2_max > s2->in_elems) return rtn_fail(h, RTN_EBOUNDS, "conv dual: second source reads reach %lld of %lld", in2_max, (long long)s2->in_elems);
+        if (s2->in_elems * es >= (long long)OOB_OFFSET) return rtn_fail(h, RTN_EINVAL, "conv dual: second source exceeds the 4 GiB descriptor range");
+        Ktot = K1 + s2->C;
+    }
     if ((Ktot * es) % 128) return rtn_fail(h, RTN_EINVAL, "conv: K=%lld elements is not a multiple of 128 bytes", Ktot);
     if (Ktot * es > (1ll << 30)) return rtn_fail(h, RTN_EINVAL, "conv: K too large");
     if (d->KH * d->KW > 4096) return rtn_fail(h, RTN_EINVAL, "conv: kernel window too large");
@@ -1118,6 +1166,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
         if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
             s.in_img_stride != (long long)s.Hin * s.in_row_stride) halo_ok = false;
     }
+    if (s2) impl = 2;                                  // only the 256-row per-tap kernel walks a second source
     if (impl == 3 && !halo_ok) impl = 2;
     // measured (tools/ab_conv.py, RTN_CONV_HALO=0|1): +3..4 % on the 256-channel 3x3 layers (heads, P3, P4, res4), none or a
     // small loss below that, so the narrower layers stay on the per-tap kernel.  RTN_CONV_HALO=2 forces it wherever it applies.
@@ -1201,6 +1250,15 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     p.Kbytes = (int)(Ktot * es);
     p.nkt = p.Kbytes / 128;
     p.cshift = cshift;
+    if (s2) {
+        p.in2 = (const char*)s2->in;
+        p.in2_bytes = (unsigned)(s2->in_elems * es);
+        p.nkt1 = (int)(K1 * es / 128);
+        p.in2_img_stride_b = s2->in_img_stride * es;
+        p.in2_row_stride_b = (int)((long long)s2->in_row_stride * es);
+        p.in2_pix_stride_b = (int)((long long)s2->pix_stride * es);
+        p.in2_step = s2->step;
+    }
     p.crun_mask = d->Crun - 1;
     p.KW = d->KW;
     p.KH = d->KH;
@@ -1294,8 +1352,23 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
     do {                                                                                                 \
         if (il) RTN_L2K(E, B, true); else RTN_L2K(E, B, false);                                          \
     } while (0)
+#define RTN_L2D(E, B)                                                                                    \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm2_kernel<E, B, false, true>,           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_igemm2_kernel<E, B, false, true>), gdim, bdim, ldsb, h->stream, p);     \
+    } while (0)
+        if (s2) {
+            if (es == 2) { if (BN == 64) RTN_L2D(2, 64); else if (BN == 128) RTN_L2D(2, 128); else RTN_L2D(2, 256); }
+            else         { if (BN == 64) RTN_L2D(4, 64); else if (BN == 128) RTN_L2D(4, 128); else RTN_L2D(4, 256); }
+        } else
         if (es == 2) { if (BN == 64) RTN_L2(2, 64); else if (BN == 128) RTN_L2(2, 128); else RTN_L2(2, 256); }
         else         { if (BN == 64) RTN_L2(4, 64); else if (BN == 128) RTN_L2(4, 128); else RTN_L2(4, 256); }
+#undef RTN_L2D
 #undef RTN_L2
 #undef RTN_L2K
     } else {
@@ -1344,6 +1417,12 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d) {
 }
 
 extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) { return conv_launch(h, d); }
+
+extern "C" int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2) {
+    if (!h) return RTN_EINVAL;
+    if (!s2) return rtn_fail(h, RTN_EINVAL, "conv dual: null second source");
+    return conv_launch(h, d, s2);
+}
 
 extern "C" int rtn_conv2d_dgrad(rtn_handle_t h, const rtn_conv_desc_t* d) {
     if (!h) return RTN_EINVAL;

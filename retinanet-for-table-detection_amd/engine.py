@@ -85,6 +85,9 @@ class Engine:
         self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
         self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
         self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
+        self.fuse_shortcut = os.environ.get("RTN_FUSE_SHORTCUT", "1") != "0"  # inference: branch1 folded into branch2c (dual-source GEMM)
+        self.weights_version = 0
+        self._dual, self._dual_version = {}, -1
         self._side = None
 
     # ------------------------------------------------------------------ weights
@@ -116,6 +119,28 @@ class Engine:
             bv.copy_(bk)
             self.w[name] = (wv, bv, kh, kw, cin, cout)
         self.plans = {}
+        self.weights_version += 1
+
+    def _dual_weights(self):
+        """K-concatenated filters of every stage's first block: [branch2c | branch1] along K, biases summed
+        (rtn_conv1x1_dual_fwd).  Copies of the flat forward weights: refreshed whenever those change (load_state, an
+        optimizer step)."""
+        if self._dual_version != self.weights_version:
+            for stage in range(4):
+                s = str(stage + 2)
+                bname = Wt.block_name(self.backbone, stage, 0)
+                wc, bc = self.w["res%s%s_branch2c" % (s, bname)][:2]
+                w1, b1 = self.w["res%s%s_branch1" % (s, bname)][:2]
+                key = "res%s%s" % (s, bname)
+                if key not in self._dual:
+                    self._dual[key] = (torch.empty(wc.shape[0], wc.shape[1] + w1.shape[1], dtype=wc.dtype, device=wc.device),
+                                       torch.empty_like(bc))
+                wd, bd = self._dual[key]
+                wd[:, :wc.shape[1]].copy_(wc)
+                wd[:, wc.shape[1]:].copy_(w1)
+                torch.add(bc, b1, out=bd)
+            self._dual_version = self.weights_version
+        return self._dual
 
     # ------------------------------------------------------------------ descriptors
     def _group(self, x, out, Hout, Wout, res=None, out_off=0, out_img_stride=None, res_hw=None):
@@ -155,6 +180,26 @@ class Engine:
                 "relu": bool(flags & L.CONV_RELU), "kh": kh, "kw": kw, "cin": cin, "cout": cout, "B": B,
                 "out_ld": d.out_ld}
         return ("conv", d, name, meta)
+
+    def _dual_op(self, fb, B):
+        """First block of a stage with the projection shortcut folded into branch2c: y = relu([W2c | W1] . [b2 ; x(step)] + b)."""
+        wd, bd = self._dual_weights()[fb["key"]]
+        f = fb["f"]
+        d = L.ConvDesc()
+        d.g[0] = self._group(fb["b2"], fb["y"], fb["Ho"], fb["Wo"])
+        d.ngroups, d.batch, d.dtype = 1, B, self.rdt
+        d.w, d.bias = wd.data_ptr(), bd.data_ptr()
+        d.w_rows, d.N, d.KH, d.KW = wd.shape[0], 4 * f, 1, 1
+        d.Crun = d.pix_stride = f
+        d.sy = d.sx = 1
+        d.pad_t = d.pad_l = 0
+        d.out_ld, d.flags = 4 * f, L.CONV_RELU
+        x = fb["x"]
+        s2 = L.ConvSrc2()
+        s2.in_, s2.in_elems = x.data_ptr(), x.numel()
+        s2.in_img_stride, s2.in_row_stride, s2.pix_stride = x.shape[1] * x.shape[2] * x.shape[3], x.shape[2] * x.shape[3], x.shape[3]
+        s2.Hin, s2.Win, s2.C, s2.step = x.shape[1], x.shape[2], x.shape[3], fb["step"]
+        return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W):
@@ -210,6 +255,7 @@ class Engine:
         n_stem_ops = len(ops)
         # ---- bottleneck stages
         feats = []
+        first_blocks = []
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
             f = 64 * 2 ** stage
             for block in range(nblocks):
@@ -224,11 +270,15 @@ class Engine:
                 if block == 0:
                     sc = buf(B, Ho, Wo, 4 * f)
                     ops.append(self._conv("res%s%s_branch1" % (s, bname), [self._group(x, sc, Ho, Wo)], B, stride=st))
+                    i_b1 = len(ops) - 1
                 else:
                     sc = x
                 y = buf(B, Ho, Wo, 4 * f)
                 ops.append(self._conv("res%s%s_branch2c" % (s, bname), [self._group(b2, y, Ho, Wo, res=sc)], B,
                                       flags=L.CONV_RELU | L.CONV_RES_SAME))
+                if block == 0:
+                    first_blocks.append({"key": "res%s%s" % (s, bname), "i_b1": i_b1, "i_2c": len(ops) - 1, "x": x, "b2": b2, "y": y,
+                                         "Ho": Ho, "Wo": Wo, "step": st, "f": f})
                 x = y
             feats.append(x)
         C3, C4, C5 = feats[1], feats[2], feats[3]
@@ -283,9 +333,21 @@ class Engine:
             tower_ranges.append((tower_start, len(ops)))
         ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
         sched = self._schedule(ops)
-        fused_ops = [ops[0], stem_fused] + ops[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
-        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep,
-                "fused_ops": fused_ops, "fused_sched": self._schedule(fused_ops), "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        variants = {}
+        for fs in (False, True):                         # fuse_stem
+            for fd in (False, True):                     # fuse_shortcut
+                if not fs and not fd:
+                    continue
+                v = list(ops)
+                if fd:
+                    for fb in first_blocks:
+                        v[fb["i_2c"]] = self._dual_op(fb, B)
+                        v[fb["i_b1"]] = None
+                if fs:
+                    v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
+                v = [op for op in v if op is not None]
+                variants[(fs, fd)] = (v, self._schedule(v))
+        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -307,6 +369,8 @@ class Engine:
             return [], [op[1].data_ptr()]
         if kind == "stem":
             return [op[5].data_ptr()], [op[1].data_ptr()]
+        if kind == "dual":
+            return [t.data_ptr() for t in op[4]["xs"]], [t.data_ptr() for t in op[4]["ys"]]
         if kind == "pool":
             return [op[1].data_ptr()], [op[2].data_ptr(), op[4].data_ptr()]
         if kind == "relu":
@@ -382,18 +446,20 @@ class Engine:
         plan = self._plan(B, H, W)
         self._bind_stream()
         fused = self._fused()
-        ops = plan["fused_ops"] if fused else plan["ops"]
+        ops = plan["variants"][fused][0] if fused else plan["ops"]
+        if fused and fused[1]:
+            self._dual_weights()                         # refresh the concatenated filters if the weights changed
         if not self.two_streams:
             for op in ops:
                 self._run_op(op, images)
             return plan["regression"], plan["classification"]
-        sched = plan["fused_sched"] if fused else plan["sched"]
+        sched = plan["variants"][fused][1] if fused else plan["sched"]
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         streams = [main] + self._side
         lanes, waits = sched["lanes"], sched["waits"]
-        events = plan.setdefault("fused_events" if fused else "events", {i: torch.cuda.Event() for i in sched["events"]})
+        events = plan.setdefault(("events", fused), {i: torch.cuda.Event() for i in sched["events"]})
         fork = plan.setdefault("fork", torch.cuda.Event())
         fork.record(main)                                    # side lanes start after everything queued before this pass
         for st in streams[1:sched["nlanes"]]:
@@ -415,17 +481,25 @@ class Engine:
         return plan["regression"], plan["classification"]
 
     def _fused(self):
-        return self.fuse_stem and not self.training and self.dtype == "bf16"
+        """(stem fused, shortcut fused) or None.  Training keeps every layer a separate launch (the backward graph needs the
+        intermediate tensors); the fused stem exists for bf16 only."""
+        if self.training:
+            return None
+        key = (self.fuse_stem and self.dtype == "bf16", self.fuse_shortcut)
+        return key if any(key) else None
 
     def active_ops(self, plan):
-        """The op list forward() executes: the training / fp32 paths keep pack, conv1, pool1 as separate launches."""
-        return plan["fused_ops"] if self._fused() else plan["ops"]
+        """The op list forward() executes."""
+        fused = self._fused()
+        return plan["variants"][fused][0] if fused else plan["ops"]
 
     def _run_op(self, op, images):
         lib, h = L.lib, self.h
         kind = op[0]
         if kind == "conv":
             h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
+        elif kind == "dual":
+            h.check(lib.rtn_conv1x1_dual_fwd(h.raw, C.byref(op[1]), C.byref(op[3])))
         elif kind == "stem":
             Bn, Hn, Wn = op[2]
             h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],

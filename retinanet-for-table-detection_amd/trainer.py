@@ -392,6 +392,7 @@ class Trainer:
                                                wf.data_ptr(), code, cnt, self.step_count, lr, self.b1, self.b2, self.eps,
                                                self.sumsq.data_ptr(), self.clipnorm, 1.0))
         self._repack_dgrad()
+        eng.weights_version += 1                        # fused inference copies of the filters are stale now
 
     def train_on_batch(self, images, regression_batch, labels_batch, lr=None):
         """Keras-style step. Returns (total, regression_loss, classification_loss) as Python floats (one host sync)."""

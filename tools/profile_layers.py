@@ -20,7 +20,7 @@ tot = 0.0
 print("%-28s %9s %9s %8s  shape" % ("op", "ms", "GFLOP", "TFLOP/s"))
 for (kind, ms), op in zip(per, eng.active_ops(plan) + [("detect",)]):
     ms /= reps; tot += ms
-    if kind == "conv":
+    if kind in ("conv", "dual"):
         d = op[1]; fl = bench.conv_flops(d, B)
         g = d.g[0]
         print("%-28s %9.4f %9.2f %8.1f  M=%d N=%d K=%d k%dx%d s%d groups=%d" % (op[2], ms, fl / 1e9, fl / ms / 1e9,
