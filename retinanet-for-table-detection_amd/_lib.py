@@ -6,6 +6,12 @@ raises, and every call checks its return code and raises RtnError with rtn_last_
 import ctypes as C
 import os
 
+# PyTorch must load ITS HIP runtime before librtn.so is opened: torch bundles libamdhip64.so (SONAME libamdhip64.so.7) and
+# librtn.so needs libamdhip64.so.7, so opened second it binds to the copy already in the process.  Opened first, the loader
+# takes /opt/rocm/lib/libamdhip64.so.7 and torch then brings a second runtime in: two HIP runtimes in one process hand each
+# other streams and pointers, and device discovery in the second one fails intermittently ("no ROCm-capable device").
+import torch  # noqa: F401  (load order, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtn.so")
 

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 
@@ -70,3 +71,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_one_hip_runtime_in_the_process():
+    """librtn.so must bind to the HIP runtime PyTorch loaded (same SONAME), not bring /opt/rocm's copy in beside it: with two
+    runtimes in one process, streams and pointers cross between them and device discovery fails intermittently.  Checked in a
+    fresh interpreter that imports the package FIRST (the order __graft_entry__.build() uses)."""
+    code = ("import importlib, sys; sys.path.insert(0, %r); importlib.import_module('retinanet-for-table-detection_amd'); import torch; "
+            "print(sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l)))" % ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], text=True).strip().splitlines()[-1]
+    libs = eval(out)
+    assert len(libs) == 1, libs
