@@ -481,11 +481,10 @@ class Engine:
         return plan["regression"], plan["classification"]
 
     def _fused(self):
-        """(stem fused, shortcut fused) or None.  Training keeps every layer a separate launch (the backward graph needs the
-        intermediate tensors); the fused stem exists for bf16 only."""
-        if self.training:
-            return None
-        key = (self.fuse_stem and self.dtype == "bf16", self.fuse_shortcut)
+        """(stem fused, shortcut fused) or None.  Training keeps conv1 / pool1 separate (the backward needs conv1's output and
+        the pooling argmax); the folded shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and
+        filters.  The fused stem exists for bf16 only."""
+        key = (self.fuse_stem and self.dtype == "bf16" and not self.training, self.fuse_shortcut)
         return key if any(key) else None
 
     def active_ops(self, plan):
