@@ -285,19 +285,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
             }
         }
     }
-    // D[row = n][col = k]: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile
+    // D[row = n][col = k]: lane holds rows 4*(lane>>4)+r, column lane&15 of each 16x16 tile.  The tile goes through this wave's
+    // LDS slice so that every atomic wave-instruction adds WT consecutive k of ONE filter row (256 contiguous bytes for bf16:
+    // the shape the memory-side atomic units run at full rate; straight from the accumulators it was 4 x 64 B).
     const int lr = (lane >> 4) * 4, lc = lane & 15;
+    constexpr int SP = WT + 1;                                   // padded row of the staging slice (floats)
+    __syncthreads();                                             // every wave is done with the operand tiles
+    float* S = reinterpret_cast<float*>(lds) + wave * (WT * SP);
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < FI; ++j) {
-            const int kc = k0 + wn * WT + 16 * j + lc;
+        for (int j = 0; j < FI; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * WT + 16 * i + lr + r;
-                if (n < p.N && kc < p.Ktot) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+            for (int r = 0; r < 4; ++r) S[(16 * i + lr + r) * SP + 16 * j + lc] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                          // this wave's LDS writes have landed (slice is wave-private)
+    if (lane < WT) {
+        const int kc = k0 + wn * WT + lane;
+        if (kc < p.Ktot) {
+#pragma unroll 4
+            for (int nl = 0; nl < WT; ++nl) {
+                const int n = n0 + wm * WT + nl;
+                if (n < p.N) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, S[nl * SP + lane]);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
