@@ -16,9 +16,9 @@
 
 namespace {
 
-constexpr int DT_T = 1024;
 constexpr int DT_MAXW = 4096;
-constexpr int DT_E = DT_MAXW / DT_T;          // columns per thread
+// threads per row sweep (DT_T) x columns per thread (DT_E) are template parameters: the launcher picks the smallest
+// workgroup that covers the page width (fewer waves = cheaper barriers and a shorter cross-wave prefix on the critical path)
 constexpr int DT_INF = (0x7fffffff >> 2);
 constexpr int DT_SHIFT = 16;
 
@@ -80,16 +80,35 @@ __device__ __forceinline__ int wave_scan_min(int v, int lane) {      // inclusiv
 
 // One workgroup = one (page, metric).  dir = +1 forward raster pass, -1 backward pass (mirror image of the same code).
 // ring[3][W]: rows y-2, y-1 (forward) or y+2, y+1 (backward) and the row being written.
-template <bool BACKWARD>
+template <bool BACKWARD, int DT_T, int DT_E>
 __device__ void dt_pass(const unsigned char* __restrict__ bin, int* __restrict__ D, int H, int W, int a, int b, int c,
                         int* ring, int* wagg, unsigned char* __restrict__ out, int ch) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int x0 = t * DT_E;
     // ring rows start as "infinity"
     for (int i = t; i < 3 * DT_MAXW; i += DT_T) ring[i] = DT_INF;
+    // The only global reads of a row step (the binary pixel, or the forward distance in the backward pass) do not depend on
+    // the recurrence: they are requested one row ahead, so their latency is off the 2*H-step critical path.
+    int pre[DT_E];
+#pragma unroll
+    for (int e = 0; e < DT_E; ++e) {
+        const int x = x0 + e, y = BACKWARD ? H - 1 : 0;
+        pre[e] = x < W ? (BACKWARD ? D[(long long)y * W + x] : (int)bin[(long long)y * W + x]) : 0;
+    }
     __syncthreads();
     for (int step = 0; step < H; ++step) {
         const int y = BACKWARD ? H - 1 - step : step;
+        int now[DT_E];
+#pragma unroll
+        for (int e = 0; e < DT_E; ++e) now[e] = pre[e];
+        if (step + 1 < H) {
+            const int yn = BACKWARD ? y - 1 : y + 1;
+#pragma unroll
+            for (int e = 0; e < DT_E; ++e) {
+                const int x = x0 + e;
+                pre[e] = x < W ? (BACKWARD ? D[(long long)yn * W + x] : (int)bin[(long long)yn * W + x]) : 0;
+            }
+        }
         const int* p1 = ring + ((step + 2) % 3) * DT_MAXW;      // previous row in sweep order
         const int* p2 = ring + ((step + 1) % 3) * DT_MAXW;      // the one before
         int* cur = ring + (step % 3) * DT_MAXW;
@@ -106,8 +125,8 @@ __device__ void dt_pass(const unsigned char* __restrict__ bin, int* __restrict__
                     tv = min(tv, min(at(p2, x - 1), at(p2, x + 1)) + c);
                     tv = min(tv, min(at(p1, x - 2), at(p1, x + 2)) + c);
                 }
-                if (BACKWARD) tv = min(tv, D[(long long)y * W + x]);
-                else if (bin[(long long)y * W + x] == 0) tv = 0;
+                if (BACKWARD) tv = min(tv, now[e]);
+                else if (now[e] == 0) tv = 0;
                 tv = min(tv, DT_INF);
             }
             // min-plus scan along the sweep direction: forward uses t - a*x, backward t + a*x scanned from the right
@@ -160,6 +179,7 @@ __device__ void dt_pass(const unsigned char* __restrict__ bin, int* __restrict__
 }
 
 // grid = B * 3 ; metric 0: DIST_L2 mask 5 -> channel 0 (b), 1: DIST_L1 -> channel 1 (g), 2: DIST_C -> channel 2 (r)
+template <int DT_T, int DT_E>
 __global__ __launch_bounds__(DT_T) void dt3_kernel(const unsigned char* __restrict__ binary, int* __restrict__ scratch, int H, int W,
                                                    unsigned char* __restrict__ out) {
     __shared__ int ring[3 * DT_MAXW];
@@ -172,9 +192,9 @@ __global__ __launch_bounds__(DT_T) void dt3_kernel(const unsigned char* __restri
     const unsigned char* bin = binary + (long long)img * H * W;
     int* D = scratch + ((long long)img * 3 + metric) * H * W;
     unsigned char* o = out + (long long)img * H * W * 3;
-    dt_pass<false>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
+    dt_pass<false, DT_T, DT_E>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
     __syncthreads();
-    dt_pass<true>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
+    dt_pass<true, DT_T, DT_E>(bin, D, H, W, a, b, c, ring, wagg, o, metric);
 }
 
 // cv2.resize(INTER_CUBIC): A = -0.75, src = (dst + 0.5)/scale - 0.5, replicate border; optional fused x/127.5 - 1 for uint8 input
@@ -241,6 +261,20 @@ bool g_gauss_uploaded[64] = {false};
 
 }  // namespace
 
+static void dt3_launch(rtn_handle_t h, const unsigned char* binary, int* scratch, int B, int H, int W, unsigned char* dst) {
+    // Measured on 2200x1712 pages (RTN_DT_CFG="T,E" is the A/B knob): the per-thread column loop, not the cross-wave prefix,
+    // is the critical path of a row step: 1024 threads x 2 columns 7.2 ms, x 4 columns 8.5, 512 x 8 12.4, 256 x 16 19.7 (8 pages).
+    // So: as many threads as columns allow, the fewest columns per thread.
+    int T = W <= 256 ? 256 : (W <= 512 ? 512 : 1024);
+    int E = (W + T - 1) / T;
+    if (const char* e = getenv("RTN_DT_CFG")) { int t_ = 0, e_ = 0; if (sscanf(e, "%d,%d", &t_, &e_) == 2 && (long long)t_ * e_ >= W) { T = t_; E = e_; } }
+    const dim3 g(B * 3);
+#define DT_GO(TT, EE) if (T == TT && E == EE) { hipLaunchKernelGGL((dt3_kernel<TT, EE>), g, dim3(TT), 0, h->stream, binary, scratch, H, W, dst); return; }
+    DT_GO(256, 1) DT_GO(512, 1) DT_GO(1024, 1) DT_GO(1024, 2) DT_GO(1024, 3) DT_GO(1024, 4) DT_GO(512, 4) DT_GO(512, 8) DT_GO(256, 8) DT_GO(256, 16)
+#undef DT_GO
+    hipLaunchKernelGGL((dt3_kernel<1024, 4>), g, dim3(1024), 0, h->stream, binary, scratch, H, W, dst);
+}
+
 extern "C" size_t rtn_preprocess_dt3_workspace_bytes(int B, int H, int W) {
     if (B < 1 || H < 1 || W < 1) return 0;
     const size_t px = (size_t)B * H * W;
@@ -278,7 +312,7 @@ extern "C" int rtn_preprocess_dt3(rtn_handle_t h, const uint8_t* src, int channe
     hipLaunchKernelGGL(vblur_threshold_kernel, dim3(grid_for((long long)px)), dim3(256), 0, h->stream, (const unsigned char*)gray, (const float*)tmp, B, H, W, 2, binary);
     RTN_CHECK_LAUNCH(h, "vblur_threshold_kernel");
     if (binary_out) RTN_HIP(h, hipMemcpyAsync(binary_out, binary, px, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(dt3_kernel, dim3(B * 3), dim3(DT_T), 0, h->stream, (const unsigned char*)binary, scratch, H, W, dst);
+    dt3_launch(h, (const unsigned char*)binary, scratch, B, H, W, dst);
     RTN_CHECK_LAUNCH(h, "dt3_kernel");
     return RTN_OK;
 }
@@ -290,7 +324,7 @@ extern "C" int rtn_distance_transform3(rtn_handle_t h, const uint8_t* binary, in
     if (!binary || !dst || !workspace || B < 1 || H < 1 || W < 1) return rtn_fail(h, RTN_EINVAL, "distance_transform3: bad argument");
     if (W > DT_MAXW || (long long)B * 3 > 65535) return rtn_fail(h, RTN_EINVAL, "distance_transform3: width %d / batch %d unsupported", W, B);
     if (workspace_bytes < (size_t)B * H * W * 12) return rtn_fail(h, RTN_ENOMEM, "distance_transform3: workspace too small");
-    hipLaunchKernelGGL(dt3_kernel, dim3(B * 3), dim3(DT_T), 0, h->stream, binary, (int*)workspace, H, W, dst);
+    dt3_launch(h, binary, (int*)workspace, B, H, W, dst);
     RTN_CHECK_LAUNCH(h, "dt3_kernel");
     return RTN_OK;
 }
