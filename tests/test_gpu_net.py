@@ -220,3 +220,27 @@ def test_fused_shortcut_matches_separate_layers(pkg, state, dtype, hw):
         err = float((a - b).abs().max())
         print("C%d: max |diff| %.3e, scale %.2f" % (lvl + 2, err, scale))
         assert scale > 0.05 and err <= tol * scale
+
+
+@pytest.mark.gpu
+def test_full_size_passes_repeat_bit_for_bit(pkg, state):
+    """BASELINE configuration (batch 8, 800x1333, bf16, every fusion and the stream lanes on): 40 back-to-back detect() calls must
+    give the same bits as the first one (the kernels are deterministic - split-K sums in slice order, no float atomics in
+    inference - so any difference is a missing cross-stream dependency or a reused buffer)."""
+    E, _ = mods(pkg)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(8, 800, 1333, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    st = dict(state)
+    st["pyramid_classification/bias"] = (state["pyramid_classification/bias"] * 0 - 2.0).astype("float32")   # a few thousand candidates
+    eng.load_state(st)
+    b0, s0, l0 = [t.clone() for t in eng.detect(x)]
+    plan = eng._plan(8, 800, 1333)
+    r0, c0 = plan["regression"].clone(), plan["classification"].clone()
+    torch.cuda.synchronize()
+    assert int((l0 >= 0).sum()) > 100
+    for _ in range(40):
+        b, s, l = eng.detect(x)
+    torch.cuda.synchronize()
+    assert torch.equal(plan["regression"], r0) and torch.equal(plan["classification"], c0)
+    assert torch.equal(b, b0) and torch.equal(s, s0) and torch.equal(l, l0)
