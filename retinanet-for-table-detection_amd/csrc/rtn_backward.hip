@@ -311,6 +311,195 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 256 x 256, LDS-DMA (bf16)
+// The loop above is bound by the L2->LDS volume of its operand loads (65 FLOP/B).  This variant owns a 256 (n) x 256 (k) tile
+// with 8 waves (4 x 2, wave tile 64 x 128): 64 KB per 64-pixel step for 8.4 MFLOP, half the volume per FLOP, and stages it by
+// LDS-DMA (no staging registers beside 128 accumulator registers; the next step's 64 KB is in flight while this one multiplies).
+// LDS image: [64 px][512 B] per operand, UNPADDED (a DMA piece is 1 KiB = 2 rows, lane-linear); the transposed reads stay
+// conflict-free through an XOR on the 32-byte granule index with key(row) = (row & 3) | ((row >> 3) & 1) << 2: the 32 lanes
+// of a half-wave read 8 rows (q = 0..3, two values of g) x one granule each, 8 distinct keys -> 8 x 8 = 64 banks.  The key
+// of the rows a lane stages does not change from piece to piece, so each lane still has ONE source chunk (tap, channel offset).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ i32x4 wd_make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void wd_dma16(const i32x4& srd, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd)
+                 : "memory");
+}
+
+constexpr int WD_ROWB = 512;
+constexpr int WD_TILE_B = 64 * WD_ROWB;       // one operand tile: 32 KB
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * WD_TILE_B];   // [stage][dY | X]
+
+    int otile, split;
+    if (p.xcd_map) {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int sl = j / p.out_tiles;
+        otile = j - sl * p.out_tiles;
+        split = sl * 8 + xcd;
+    } else {
+        otile = blockIdx.x;
+        split = blockIdx.y;
+    }
+    const int tile_n = otile / p.ntiles_k;
+    const int tile_k = otile - tile_n * p.ntiles_k;
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int tlo = split * p.tiles_per_split;
+    int thi = tlo + p.tiles_per_split;
+    thi = thi < p.total_tiles ? thi : p.total_tiles;
+    if (tlo >= thi) return;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // ---- staging role: piece i of this wave = rows 2*(wave + 8i) + (lane >> 5), LDS chunk position lane & 31
+    const int rsub = lane >> 5;
+    const int srow0 = 2 * wave + rsub;                         // + 16 i
+    const int skey = (srow0 & 3) | (((srow0 >> 3) & 1) << 2);  // the same for every i (16 i keeps row & 3 and flips nothing in bit 3 pairs)
+    const int sc = (lane & 31) ^ (skey << 1);                  // source chunk (8 elements) this lane fetches
+    const int kk = k0 + sc * 8;
+    const bool kvalid = kk < p.Ktot;
+    const int kpos = kk >> p.cshift;
+    const int coff = kk & p.crun_mask;
+    const int kh = (kpos * p.kw_inv) >> 16;
+    const int kw = kpos - kh * p.KW;
+    const int nn = n0 + sc * 8;
+    const bool nvalid = nn < p.N;
+    const unsigned dyo = (unsigned)(nn * 2);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db != nullptr && tile_k == 0 && wn == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    uint4 ri[4];
+#define WD_ROWINFO(TILE)                                                                                            \
+    {                                                                                                               \
+        const int tt_ = (TILE) < thi ? (TILE) : thi - 1;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ri[i_] = p.rowinfo[(long long)tt_ * 64 + srow0 + 16 * i_]; \
+    }
+#define WD_STAGE(TILE, STG)                                                                                         \
+    {                                                                                                               \
+        int gi_ = 0;                                                                                                \
+        _Pragma("unroll") for (int i_ = 1; i_ < RTN_MAX_GROUPS; ++i_)                                               \
+            if (i_ < p.ngroups && (TILE) >= p.g[i_].tile_begin) gi_ = i_;                                           \
+        const WGroup& G_ = p.g[gi_];                                                                                \
+        const i32x4 xs_ = wd_make_srd(G_.x, G_.x_bytes);                                                            \
+        const i32x4 ys_ = wd_make_srd(G_.dy, G_.dy_bytes);                                                          \
+        const unsigned delta_ = (unsigned)(kh * G_.x_row_stride_b + kw * p.pix_stride_b + coff * 2);                \
+        const int Hin_ = G_.Hin, Win_ = G_.Win;                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+            const int iy_ = (int)(short)(ri[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri[i_].z >> 16) + kw;         \
+            const bool ok_ = kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;            \
+            const unsigned piece_ = (unsigned)((wave + 8 * i_) * 1024);                                             \
+            wd_dma16(ys_, (nvalid && ri[i_].y != OOB_OFFSET) ? ri[i_].y + dyo : OOB_OFFSET,                         \
+                     lds_base + (unsigned)((STG) * 2 * WD_TILE_B) + piece_);                                        \
+            wd_dma16(xs_, ok_ ? ri[i_].x + delta_ : OOB_OFFSET,                                                     \
+                     lds_base + (unsigned)((STG) * 2 * WD_TILE_B + WD_TILE_B) + piece_);                            \
+        }                                                                                                           \
+    }
+
+    WD_ROWINFO(tlo);
+    WD_STAGE(tlo, 0);
+    WD_ROWINFO(tlo + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rkey = q | ((g & 1) << 2);
+    int cur = 0;
+#pragma unroll 1
+    for (int tile = tlo; tile < thi; ++tile) {
+        if (tile + 1 < thi) {
+            WD_STAGE(tile + 1, cur ^ 1);
+            WD_ROWINFO(tile + 2);
+        }
+        const char* A = lds + cur * 2 * WD_TILE_B;     // dY tile
+        const char* B = A + WD_TILE_B;                 // X tile
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = 32 * s + 8 * g + q;
+            s16x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;            // byte column inside the 512-byte row
+                const int aoff = row * WD_ROWB + (((ca >> 5) ^ rkey) << 5) + (ca & 31);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WD_ROWB));
+                af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            if (do_bias) {                              // BiasAddGrad: the A fragment of lane (m, kq) holds 8 pixels of channel m
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((unsigned)(unsigned short)af[i][e]) << 16);
+            }
+#pragma unroll
+            for (int jh = 0; jh < 8; jh += 4) {
+                s16x8 bf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cb = (wn * 128 + 16 * (jh + j) + 4 * pp) * 2;
+                    const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
+                    const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
+                    const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
+                    bf[j] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                                 __builtin_bit_cast(bf16x8, bf[j]), acc[i][jh + j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage (and the row info behind it) has landed
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef WD_STAGE
+#undef WD_ROWINFO
+
+    const int lr = (lane >> 4) * 4, lc = lane & 15;
+    if (do_bias) {       // lane (m = lane & 15, kq = lane >> 4): fold the four pixel groups, lanes 0..15 add channel m
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wm * 64 + 16 * i + lc;
+            if (lane < 16 && n < p.db_n) unsafeAtomicAdd(p.db + n, v);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kc = k0 + wn * 128 + 16 * j + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 64 + 16 * i + lr + r;
+                if (n < p.N && kc < p.Ktot) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 template <int ES>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const char* __restrict__ dy, long long rows, int N, long long ld_b,
@@ -823,7 +1012,16 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         tiles += (cells * d->batch + 63) / 64;
     }
     if (tiles > (1 << 24)) return rtn_fail(h, RTN_EINVAL, "wgrad: too many pixels");
-    const int CH = es == 2 ? 128 : 64;
+    // bf16 layers with more than 128 filters and at least one 256-wide K tile: the 256 x 256 LDS-DMA kernel (RTN_WGRAD_DMA=0: off)
+    // Measured per layer (tools/profile_train.py, batch 16): -27 % on the head layers (5575 pixel tiles, 0.71 -> 0.52 ms) and
+    // -21 % on P3, but +25..40 % on the layers with ~1000 pixel tiles or fewer (res4/res5, C4/C5, P5, P6: short loops, and each
+    // workgroup ends with 128 accumulator registers of atomics), hence the pixel-count condition.
+    bool dma = es == 2 && d->N > 128 && Ktot >= 256 && tiles >= 2048;
+    if (const char* e = getenv("RTN_WGRAD_DMA")) {          // 0: never; 2: wherever the shape allows (tests, A/B)
+        const int v = atoi(e);
+        dma = v == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (dma && v != 0);
+    }
+    const int CH = dma ? 256 : (es == 2 ? 128 : 64);
     p.dW = dW;
     p.db = db;
     p.db_n = db_n;
@@ -846,7 +1044,7 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     // on 1024 slots cost a third round (training step 40.8 -> 38.8 ms).  RTN_WGRAD_BLOCKS overrides the target.
     // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
     // bound by the latency of its register-staged loads, not by MFMA work per byte.)
-    const long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * 2;
+    const long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * (dma ? 1 : 2);
     long long target = slots * 2;
     if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
     long long nsplit = target / out_tiles;
@@ -868,8 +1066,9 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.out_tiles = (int)out_tiles;
     p.xcd_map = xcd_map ? 1 : 0;
     dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
-    if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
-    else         hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
+    if (dma)          hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid, dim3(512), 0, h->stream, p);
+    else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
+    else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
     return RTN_OK;
 }

@@ -311,3 +311,57 @@ def test_adam_clipnorm_matches_keras_formula(pkg, handle, fwd):
     assert torch.equal(wd.cpu()[::17], w0[::17])                                   # zero-scaled slots never move
     wantf = (wd.cpu() * fold).to(tdt)
     assert float((wf.cpu().float() - wantf.float()).abs().max()) <= (1e-6 if fwd == "f32" else 1e-2)
+
+
+@pytest.mark.parametrize("case", [2, 4, 5])
+def test_wgrad_dma_kernel_cases(pkg, handle, monkeypatch, case):
+    """RTN_WGRAD_DMA=2 sends every bf16 layer with more than 128 filters to the 256 x 256 LDS-DMA wgrad kernel (by default only
+    layers with >= 2048 pixel tiles take it): the same cases as above, incl. stride 2 and the fused bias gradient."""
+    monkeypatch.setenv("RTN_WGRAD_DMA", "2")
+    test_dgrad_and_wgrad(pkg, handle, "bf16", case)
+
+
+def test_wgrad_dma_grouped_levels_match_the_small_kernel(pkg, handle, monkeypatch):
+    """A head hidden layer (256 -> 256, 3x3, five pyramid levels in one launch, bias gradient fused): the two wgrad kernels
+    must agree to f32 summation order (both add bf16 x bf16 products in f32; stated 1e-4 of the largest gradient)."""
+    L = pkg._lib
+    tdt, code = DT["bf16"]
+    B, cin, cout = 3, 256, 256
+    levels = [(23, 31), (12, 16), (6, 8), (3, 4), (2, 2)]
+    g = torch.Generator().manual_seed(17)
+    total = sum(h * w for h, w in levels)
+    dy = torch.randn(B, total, cout, generator=g).to(tdt).to(DEV).contiguous()
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w_rows, d.N, d.KH, d.KW = 256, cout, 3, 3
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = 1
+    d.out_ld = cout
+    keep, off = [], 0
+    for gi, (H, W) in enumerate(levels):
+        xd = torch.randn(B, H, W, cin, generator=g).to(tdt).to(DEV).contiguous()
+        keep.append(xd)
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems = dy.data_ptr(), dy.numel()
+        grp.out_img_stride, grp.out_off = total * cout, off * cout
+        d.g[gi] = grp
+        off += H * W
+    wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    got = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("RTN_WGRAD_DMA", mode)
+        dW = torch.zeros(256, 9 * cin, dtype=torch.float32, device=DEV)
+        db = torch.zeros(256, dtype=torch.float32, device=DEV)
+        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        torch.cuda.synchronize()
+        got[mode] = (dW.cpu().double(), db.cpu().double())
+    for a, b in zip(got["0"], got["2"]):
+        scale = float(a.abs().max())
+        assert scale > 1.0 and float((a - b).abs().max()) <= 1e-4 * scale
+    want_db = dy.float().cpu().double().sum(dim=(0, 1))
+    assert float((got["2"][1] - want_db).abs().max()) <= 1e-4 * float(want_db.abs().max())

@@ -58,5 +58,5 @@ for b in bp["bops"]:
 tot = collections.Counter()
 for k, v in acc.items(): tot[k.split(":")[0]] += v
 print("backward by kind:", {k: round(v, 3) for k, v in tot.items()}, "sum %.3f ms" % sum(tot.values()))
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:25]: print("  %-40s %.3f ms" % (k, v))
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:400]: print("  %-40s %.3f ms" % (k, v))
 print("optimizer    %.3f ms" % timed(lambda: tr.optimizer_step()))
