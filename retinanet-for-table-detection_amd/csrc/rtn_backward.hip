@@ -338,10 +338,19 @@ __device__ __forceinline__ void wd_dma16(const i32x4& srd, unsigned voff, unsign
                  : "memory");
 }
 
-constexpr int WD_ROWB = 512;
-constexpr int WD_TILE_B = 64 * WD_ROWB;       // one operand tile: 32 KB
-
-__global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p) {
+// NWN x NWK waves, wave tile 64 (n) x 16*FJ (k); square tiles only: TS = 64*NWN = 16*FJ*NWK channels per side.
+//   <4, 2, 8>: 256 x 256, 512 threads, 128 KB of LDS  (many-pixel layers)
+//   <2, 2, 4>: 128 x 128, 256 threads,  64 KB of LDS  (two workgroups per CU)
+template <int NWN, int NWK, int FJ>
+__global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const WParams p) {
+    constexpr int NW = NWN * NWK;
+    constexpr int TS = 64 * NWN;
+    static_assert(TS == 16 * FJ * NWK, "square output tile");
+    constexpr int WD_ROWB = TS * 2;               // bytes per pixel row of an operand tile
+    constexpr int WD_TILE_B = 64 * WD_ROWB;
+    constexpr int CPR = WD_ROWB / 16;             // 16-byte chunks per row
+    constexpr int RPP = 1024 / WD_ROWB;           // rows per 1-KiB staging piece
+    static_assert(RPP * NW == 16 && 64 / (RPP * NW) == 4, "four pieces per wave and operand, 16 rows apart");
     __shared__ __attribute__((aligned(16))) char lds[4 * WD_TILE_B];   // [stage][dY | X]
 
     int otile, split;
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
     }
     const int tile_n = otile / p.ntiles_k;
     const int tile_k = otile - tile_n * p.ntiles_k;
-    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int n0 = tile_n * TS, k0 = tile_k * TS;
     const int tlo = split * p.tiles_per_split;
     int thi = tlo + p.tiles_per_split;
     thi = thi < p.total_tiles ? thi : p.total_tiles;
@@ -364,11 +373,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // ---- staging role: piece i of this wave = rows 2*(wave + 8i) + (lane >> 5), LDS chunk position lane & 31
-    const int rsub = lane >> 5;
-    const int srow0 = 2 * wave + rsub;                         // + 16 i
-    const int skey = (srow0 & 3) | (((srow0 >> 3) & 1) << 2);  // the same for every i (16 i keeps row & 3 and flips nothing in bit 3 pairs)
-    const int sc = (lane & 31) ^ (skey << 1);                  // source chunk (8 elements) this lane fetches
+    // ---- staging role: piece i of this wave = rows RPP*(wave + NW*i) + lane / CPR, LDS chunk position lane % CPR
+    const int rsub = lane / CPR;
+    const int srow0 = RPP * wave + rsub;                       // + 16 i
+    const int skey = (srow0 & 3) | (((srow0 >> 3) & 1) << 2);  // the same for every i (+16 keeps row & 3 and bit 3)
+    const int sc = (lane % CPR) ^ (skey << 1);                 // source chunk (8 elements) this lane fetches
     const int kk = k0 + sc * 8;
     const bool kvalid = kk < p.Ktot;
     const int kpos = kk >> p.cshift;
@@ -380,12 +389,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
     const unsigned dyo = (unsigned)(nn * 2);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[4][8];
+    const int wm = wave / NWK, wn = wave % NWK;
+    f32x4 acc[4][FJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = p.db != nullptr && tile_k == 0 && wn == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
             const int iy_ = (int)(short)(ri[i_].z & 0xffffu) + kh, ix_ = (int)(short)(ri[i_].z >> 16) + kw;         \
             const bool ok_ = kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;            \
-            const unsigned piece_ = (unsigned)((wave + 8 * i_) * 1024);                                             \
+            const unsigned piece_ = (unsigned)((wave + NW * i_) * 1024);                                             \
             wd_dma16(ys_, (nvalid && ri[i_].y != OOB_OFFSET) ? ri[i_].y + dyo : OOB_OFFSET,                         \
                      lds_base + (unsigned)((STG) * 2 * WD_TILE_B) + piece_);                                        \
             wd_dma16(xs_, ok_ ? ri[i_].x + delta_ : OOB_OFFSET,                                                     \
@@ -451,11 +460,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
                     for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((unsigned)(unsigned short)af[i][e]) << 16);
             }
 #pragma unroll
-            for (int jh = 0; jh < 8; jh += 4) {
+            for (int jh = 0; jh < FJ; jh += 4) {
                 s16x8 bf[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int cb = (wn * 128 + 16 * (jh + j) + 4 * pp) * 2;
+                    const int cb = (wn * 16 * FJ + 16 * (jh + j) + 4 * pp) * 2;
                     const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
                     const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
                     const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
@@ -490,8 +499,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_dma_kernel(const WParams p)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kc = k0 + wn * 128 + 16 * j + lc;
+        for (int j = 0; j < FJ; ++j) {
+            const int kc = k0 + wn * 16 * FJ + 16 * j + lc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wm * 64 + 16 * i + lr + r;
@@ -1021,6 +1030,10 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         const int v = atoi(e);
         dma = v == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (dma && v != 0);
     }
+    // the same staging on the 128 x 128 tile for the other bf16 layers with whole 128-wide tiles (RTN_WGRAD_DMA_SMALL=0: register-staged kernel)
+    bool dma_small = !dma && es == 2;                      // measured: train step 37.4 -> 36.8 ms against the register-staged kernel
+    if (const char* e = getenv("RTN_WGRAD_DMA_SMALL")) dma_small = dma_small && atoi(e) != 0;
+    if (const char* e = getenv("RTN_WGRAD_DMA")) { if (atoi(e) == 0) dma_small = false; }
     const int CH = dma ? 256 : (es == 2 ? 128 : 64);
     p.dW = dW;
     p.db = db;
@@ -1066,7 +1079,8 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.out_tiles = (int)out_tiles;
     p.xcd_map = xcd_map ? 1 : 0;
     dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
-    if (dma)          hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid, dim3(512), 0, h->stream, p);
+    if (dma)            hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
+    else if (dma_small) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2, 4>), grid, dim3(256), 0, h->stream, p);
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
