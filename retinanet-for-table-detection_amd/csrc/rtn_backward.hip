@@ -1058,7 +1058,7 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
     // bound by the latency of its register-staged loads, not by MFMA work per byte.)
     const long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * (dma ? 1 : 2);
-    long long target = slots * 2;
+    long long target = slots * (dma_small ? 1 : 2);      // measured (RTN_WGRAD_BLOCKS sweep): one round for the 128 x 128 DMA kernel (fewer atomics)
     if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
     long long nsplit = target / out_tiles;
     if (nsplit > tiles) nsplit = tiles;
