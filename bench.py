@@ -26,6 +26,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / cross-process GPU sharing on this pool needs dmabuf IPC
 PKG = "retinanet-for-table-detection_amd"
 
 CANVAS = (800, 1333)
