@@ -546,9 +546,15 @@ class Engine:
         reg, cls = self.forward(images)
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)
-        self.postprocess(plan["cfg"], reg, cls, H, W, plan["boxes"], plan["scores"], plan["labels"], plan["det_ws"],
-                         score_threshold, nms_threshold, max_detections)
-        return plan["boxes"], plan["scores"], plan["labels"]
+        md = int(max_detections)
+        if not 1 <= md <= L.RTN_MAX_DET:
+            raise ValueError("max_detections must be in [1, %d]" % L.RTN_MAX_DET)
+        # the library writes (B, max_detections, .) densely: hand it views of that shape over the plan's buffers
+        boxes = plan["boxes"].view(-1)[:B * md * 4].view(B, md, 4)
+        scores = plan["scores"].view(-1)[:B * md].view(B, md)
+        labels = plan["labels"].view(-1)[:B * md].view(B, md)
+        self.postprocess(plan["cfg"], reg, cls, H, W, boxes, scores, labels, plan["det_ws"], score_threshold, nms_threshold, md)
+        return boxes, scores, labels
 
     def postprocess(self, cfg, regression, classification, H, W, boxes, scores, labels, ws, score_threshold=0.05,
                     nms_threshold=0.5, max_detections=300):
