@@ -278,3 +278,45 @@ def test_map_of_the_device_paths_against_the_float64_oracle(pkg, state):
         print("%s path vs float64 oracle detections: AP50 %.4f AP75 %.4f AP90 %.4f" % (dtype, *aps))
         for ap, floor in zip(aps, floors):
             assert ap >= floor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,B,hw,src,thr,nms,md", [
+    (3, 1, (97, 131), "f32", 0.05, 0.5, 300),     # odd canvas, three classes, one image
+    (1, 3, (224, 160), "u8", 0.30, 0.3, 17),      # portrait canvas, uint8 pages, tight thresholds, 17 detections
+    (2, 2, (64, 64), "bf16", 0.60, 0.7, 100),     # tiny canvas: P6/P7 are 1x1 and 1x1
+])
+def test_detect_parameters_and_shapes(pkg, K, B, hw, src, thr, nms, md):
+    """End to end on unusual shapes and detection parameters: the post-processing must equal the oracle's filter_detections on
+    the engine's own head outputs bit for bit (model/layers.py:177-264), whatever the class count, thresholds or
+    max_detections; the head outputs stay within the bf16 tolerance of the bf16-emulating oracle."""
+    E, Wt = mods(pkg)
+    st = Wt.init_state("resnet50", K, 9, seed=3, randomize_bn=True, cls_bias=0.5, tame=True)
+    g = torch.Generator().manual_seed(9)
+    u8 = torch.randint(0, 256, (B, hw[0], hw[1], 3), generator=g, dtype=torch.uint8)
+    xf = torch.as_tensor(R.preprocess_custom_tf(u8.numpy()))
+    x = {"u8": u8, "f32": xf, "bf16": xf.to(torch.bfloat16)}[src].cuda()
+    eng = E.Engine("resnet50", K, 9, dtype="bf16")
+    eng.load_state(st)
+    boxes, scores, labels = eng.detect(x, score_threshold=thr, nms_threshold=nms, max_detections=md)
+    torch.cuda.synchronize()
+    assert boxes.shape == (B, md, 4) and scores.shape == (B, md) and labels.shape == (B, md)
+    plan = eng._plan(B, hw[0], hw[1])
+    reg, cls = plan["regression"].cpu().numpy(), plan["classification"].cpu().numpy()
+    assert cls.shape == (B, plan["N"], K)
+    a32 = R.anchors_f32(hw + (3,))
+    n_det = 0
+    for b in range(B):
+        wb, ws, wl = R.filter_detections(R.decode_boxes_f32(a32, reg[b], hw), cls[b], score_threshold=thr, max_detections=md,
+                                         nms_threshold=nms)
+        assert np.array_equal(boxes[b].cpu().numpy(), wb) and np.array_equal(scores[b].cpu().numpy(), ws)
+        assert np.array_equal(labels[b].cpu().numpy(), wl)
+        n_det += int((ws >= 0).sum())
+    assert n_det > 0
+    xin = xf if src != "bf16" else xf.to(torch.bfloat16).float()
+    ereg, ecls = RefNet(st, num_classes=K, dtype=torch.float32, emulate_bf16=True).forward(xin.numpy())
+    dbox = np.abs(np.stack([R.decode_boxes_f32(a32, reg[b], hw) for b in range(B)]).astype(np.float64) -
+                  np.stack([R.decode_boxes_f32(a32, ereg.numpy()[b], hw) for b in range(B)])).max()
+    dcls = np.abs(cls - ecls.numpy()).max()
+    print("K=%d B=%d %s %s: box %.3e px, score %.3e, %d detections" % (K, B, hw, src, dbox, dcls, n_det))
+    assert dbox <= 2.0 and dcls <= 2e-2
