@@ -115,6 +115,11 @@ struct KParams {
     int nkt1;
     long long in2_img_stride_b;
     int in2_row_stride_b, in2_pix_stride_b, in2_step;
+    // tail split (256-row kernels, one group): the last `tail_tiles` tiles of a grid that is a few tiles over a whole number
+    // of rounds are cut into `tail_slices` K slices each (extra workgroups of the SAME launch write f32 partial sums in
+    // register layout to `scratch`); a second, tiny launch of the same kernel (tail_mode 2) sums the slices in order and runs
+    // the epilogue.  tail_mode: 0 off, 1 main launch, 2 finish launch.
+    int tail_mode, tail_main, tail_tiles, tail_slices, tail_per;   // tail_per: K steps (v2) / (kh,chunk) groups (v3) per slice
     int korder_chunks, korder_kw;   // 256-row kernel: K-step visiting order (see KOrder in the kernel); {nkt, 1} = in order
 };
 
@@ -576,11 +581,19 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(STAGE_BYTES == 2 * SB && EPI_BYTES <= 160 * 1024 && STAGE_BYTES <= 160 * 1024, "LDS budget");
 
-    int wg;
+    int wg, slice = -1;                               // slice >= 0: this workgroup computes one K slice of a tail tile
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int nwg = p.tail_mode == 1 ? p.tail_main : gridDim.x, bid = blockIdx.x;
+        if (p.tail_mode == 2) {
+            wg = p.tail_main + bid;
+        } else if (p.tail_mode == 1 && bid >= p.tail_main) {
+            const int idx = bid - p.tail_main;
+            wg = p.tail_main + idx / p.tail_slices;
+            slice = idx - (idx / p.tail_slices) * p.tail_slices;
+        } else {
+            const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
     }
     const int mtile_g = wg / p.ntiles_n;
     const int ntile = wg - mtile_g * p.ntiles_n;
@@ -712,7 +725,21 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 
     // Staging ring of `nst` stages: steps kt+1 .. kt+nst-1 are in flight while step kt is multiplied, so a step
     // costs max(MFMA time, DMA latency / (nst-1)) instead of their sum on the narrow tiles.
-    const int nkt = p.nkt;
+    int klo = 0, khi = p.nkt;                         // K steps (in visiting order) of this workgroup
+    if (slice >= 0) {
+        klo = slice * p.tail_per;
+        khi = klo + p.tail_per < p.nkt ? klo + p.tail_per : p.nkt;
+    } else if (p.tail_mode == 2) {
+        khi = 0;                                      // finish launch: the sums come from the slabs
+    }
+    const int nkt = khi - klo;
+    if (klo > 0) {                                    // position of the iterator at visiting index klo
+        const int per_row = ko_kw_n * ko_nchunk;
+        ko_row = klo / per_row;
+        const int rem_ = klo - ko_row * per_row;
+        ko_cc = rem_ / ko_kw_n;
+        ko_kw = rem_ - ko_cc * ko_kw_n;
+    }
     const int nst = p.nstages;
     for (int s_ = 0; s_ < nst - 1 && s_ < nkt; ++s_) {
         RTN_TAPS(RTN_KO_POS());
@@ -771,6 +798,29 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #undef RTN_DMA
 #undef RTN_KO_POS
 #undef RTN_KO_NEXT
+
+    if (p.tail_mode != 0 && wg >= p.tail_main) {      // tail tile: partial sums travel through f32 slabs in register layout
+        f32x4* slab = reinterpret_cast<f32x4*>(p.scratch);
+        const long long tl = (long long)(wg - p.tail_main) * p.tail_slices;
+        if (slice >= 0) {
+            f32x4* dst = slab + (((tl + slice) * 8 + wave) * (MI * NI)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) dst[(i * NI + j) * 64] = acc[i][j];
+            return;
+        }
+        for (int sl = 0; sl < p.tail_slices; ++sl) {  // finish launch: slices in order (bitwise reproducible)
+            const f32x4* src = slab + (((tl + sl) * 8 + wave) * (MI * NI)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const f32x4 v = src[(i * NI + j) * 64];
+                    acc[i][j][0] += v[0]; acc[i][j][1] += v[1]; acc[i][j][2] += v[2]; acc[i][j][3] += v[3];
+                }
+        }
+    }
 
     // ---- wave-private epilogue: 2 halves of 32 rows through this wave's LDS slice
     float* S = reinterpret_cast<float*>(lds + wave * EPI_WAVE_BYTES);
@@ -837,11 +887,19 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
     constexpr int EPI_WAVE_BYTES = 32 * SLDW * 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 A halos, 2 B tiles (>= the epilogue slices)
 
-    int wg;
+    int wg, slice = -1;                               // slice >= 0: this workgroup computes one K slice of a tail tile
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int nwg = p.tail_mode == 1 ? p.tail_main : gridDim.x, bid = blockIdx.x;
+        if (p.tail_mode == 2) {
+            wg = p.tail_main + bid;
+        } else if (p.tail_mode == 1 && bid >= p.tail_main) {
+            const int idx = bid - p.tail_main;
+            wg = p.tail_main + idx / p.tail_slices;
+            slice = idx - (idx / p.tail_slices) * p.tail_slices;
+        } else {
+            const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+            wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
     }
     const int mtile_g = wg / p.ntiles_n;
     const int ntile = wg - mtile_g * p.ntiles_n;
@@ -937,12 +995,21 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
     }
 
     // B ring of `nbst` stages (2 or 3): the B tile of step kt + nbst - 1 is staged while step kt is multiplied.
-    const int nkt = p.nkt;
+    // (kh, chunk) groups of this workgroup: all of them, or one slice of a tail tile, or none (finish launch)
+    int g_lo = 0, g_hi = p.KH * nchunk;
+    if (slice >= 0) {
+        g_lo = slice * p.tail_per;
+        g_hi = g_lo + p.tail_per < g_hi ? g_lo + p.tail_per : g_hi;
+    } else if (p.tail_mode == 2) {
+        g_hi = 0;
+    }
+    const int nkt = (g_hi - g_lo) * KWn;
     const int nbst = p.nstages;
-    int kh = 0, cc = 0, kw = 0;                       // the step being multiplied
-    int nkh = 0, ncc = 0, nkw = 0;                    // the step whose B tile is staged next
+    int kh = g_lo / nchunk, cc = g_lo - (g_lo / nchunk) * nchunk, kw = 0;   // the step being multiplied
+    int nkh = kh, ncc = cc, nkw = 0;                  // the step whose B tile is staged next
+    int gcur = g_lo;                                  // group of the step being multiplied
     int abuf = 0, bcur = 0, bnxt = 0;
-    RTN_A_STAGE(0, 0, 0);
+    if (nkt > 0) RTN_A_STAGE(0, kh, cc);
     for (int s_ = 0; s_ < nbst - 1 && s_ < nkt; ++s_) {
         RTN_B_STAGE(bnxt, nkh, ncc, nkw);
         if (++nkw == KWn) { nkw = 0; if (++ncc == nchunk) { ncc = 0; ++nkh; } }
@@ -964,7 +1031,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
         if (kw == 0) {                                // first step of a group: stage the NEXT group's halo behind the B tile
             int gkh = kh, gcc = cc + 1;
             if (gcc == nchunk) { gcc = 0; ++gkh; }
-            if (gkh < p.KH) { RTN_A_STAGE(abuf ^ 1, gkh, gcc); a_now = true; }
+            if (gcur + 1 < g_hi) { RTN_A_STAGE(abuf ^ 1, gkh, gcc); a_now = true; }
         }
         const int rr = a_row + kw;                    // LDS row of this lane's first fragment row for tap kw
         const int swz = rr & 7;
@@ -1006,10 +1073,33 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
         a_prev = a_now;
         __syncthreads();
         bcur = bcur + 1 == nbst ? 0 : bcur + 1;
-        if (++kw == KWn) { kw = 0; abuf ^= 1; if (++cc == nchunk) { cc = 0; ++kh; } }
+        if (++kw == KWn) { kw = 0; abuf ^= 1; ++gcur; if (++cc == nchunk) { cc = 0; ++kh; } }
     }
 #undef RTN_A_STAGE
 #undef RTN_B_STAGE
+
+    if (p.tail_mode != 0 && wg >= p.tail_main) {      // tail tile: partial sums travel through f32 slabs in register layout
+        f32x4* slab = reinterpret_cast<f32x4*>(p.scratch);
+        const long long tl = (long long)(wg - p.tail_main) * p.tail_slices;
+        if (slice >= 0) {
+            f32x4* dst = slab + (((tl + slice) * 8 + wave) * (MI * NI)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) dst[(i * NI + j) * 64] = acc[i][j];
+            return;
+        }
+        for (int sl = 0; sl < p.tail_slices; ++sl) {  // finish launch: slices in order (bitwise reproducible)
+            const f32x4* src = slab + (((tl + sl) * 8 + wave) * (MI * NI)) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const f32x4 v = src[(i * NI + j) * 64];
+                    acc[i][j][0] += v[0]; acc[i][j][1] += v[1]; acc[i][j][2] += v[2]; acc[i][j][3] += v[3];
+                }
+        }
+    }
 
     // ---- wave-private epilogue (rows beyond TM belong to the next tile)
     float* S = reinterpret_cast<float*>(lds + wave * EPI_WAVE_BYTES);
@@ -1290,6 +1380,43 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (grid < 1 || grid > 0x7fffffffll) return rtn_fail(h, RTN_EINVAL, "conv: grid %lld", grid);
 
     dim3 gdim((unsigned)grid);
+    // ---- tail split (see KParams): the grid is a few tiles over a whole number of rounds of the resident slots
+    int tail_tiles = 0;
+    if (impl >= 2 && d->ngroups == 1 && !s2 && rtn_env_int("RTN_CONV_TAIL", 1) != 0) {
+        long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * (BN == 64 ? 2 : 1);
+        { const int sl_env = rtn_env_int("RTN_CONV_TAIL_SLOTS", 0); if (sl_env > 0) slots = sl_env; }   // tests: pretend a small chip
+        const long long rest = grid % slots;
+        const int units = impl == 3 ? d->KH * (d->Crun * es / 128) : p.nkt;      // (kh, chunk) groups | K steps
+        const int min_units = impl == 3 ? 1 : 2;
+        // measured (tools/ab_conv.py RTN_CONV_TAIL=0|1): -13 % on res4 3x3 / P4, -5 % on the res4 1x1 (one full round + a few tiles);
+        // +3..5 % where two or more full rounds precede the tail (res2, res3, C3: the extra launch costs more than the short
+        // last round), so only grids between one and two rounds are split
+        if (grid > slots && grid < 2 * slots && rest > 0 && rest * 4 <= slots && units >= 4 * min_units) {
+            long long S = slots / rest;
+            if (S > units / min_units) S = units / min_units;
+            if (S > 16) S = 16;
+            const int per = (int)((units + S - 1) / S);
+            S = (units + per - 1) / per;
+            const long long slab_bytes = rest * S * (long long)BM2 * BN * 4;
+            float* scratch = S >= 2 ? rtn_splitk_scratch(h) : nullptr;
+            if (scratch && slab_bytes <= (long long)h->splitk_bytes) {
+                tail_tiles = (int)rest;
+                p.tail_mode = 1;
+                p.tail_main = (int)(grid - rest);
+                p.tail_tiles = tail_tiles;
+                p.tail_slices = (int)S;
+                p.tail_per = per;
+                p.scratch = scratch;
+                gdim = dim3((unsigned)(grid - rest + rest * S));
+            }
+        }
+    }
+    for (int pass = 0; pass < (tail_tiles ? 2 : 1); ++pass) {
+    if (pass == 1) {                                   // the finish launch: one workgroup per tail tile
+        RTN_CHECK_LAUNCH(h, "conv (tail-split main launch)");
+        p.tail_mode = 2;
+        gdim = dim3((unsigned)tail_tiles);
+    }
     if (impl == 3) {
         dim3 bdim(NT2);
         const unsigned epib = 8u * 32u * (unsigned)(BN / 2 + 4) * 4u;
@@ -1371,7 +1498,9 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
 #undef RTN_L2D
 #undef RTN_L2
 #undef RTN_L2K
-    } else {
+    }
+    }   // pass
+    if (impl < 2) {
         dim3 bdim(NT);
         // split-K: a long K loop on a grid that cannot fill the chip (P6: 36 workgroups x 288 K steps)
         int ksplit = 1;

@@ -201,6 +201,34 @@ def test_conv3x3_every_kernel_generation(pkg, handle, monkeypatch, dtype, case, 
     check(gots, wants, ld, n, dtype)
 
 
+@pytest.mark.parametrize("impl", [2, 3])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("levels,cin,cout,k,res,B,slots", [
+    ([(25, 42)], 256, 256, 3, None, 3, 50),        # 13 row tiles x 4 column tiles (64 wide) = 52 tiles on 50 "slots": 2 tail tiles
+    ([(31, 47)], 512, 192, 1, "same", 2, 34),      # 1x1, K = 8 steps, N not a tile multiple (36 tiles), shortcut add in the finish launch
+    ([(40, 67)], 256, 256, 3, "up", 1, 42),        # 44 tiles
+])
+def test_tail_split(pkg, handle, monkeypatch, dtype, impl, levels, cin, cout, k, res, B, slots):
+    """A grid a few tiles over a whole number of rounds gives its last tiles to K-slice workgroups of the same launch (f32
+    slabs) and a finish launch that sums the slices in order and runs the epilogue.  RTN_CONV_TAIL_SLOTS pretends the chip
+    has that many resident slots so that these small layers take that path; the result must still match the reference."""
+    if impl == 3 and k == 1:
+        pytest.skip("the halo kernel is for KW >= 2")
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", str(impl))
+    monkeypatch.setenv("RTN_CONV_BN2", "64")
+    monkeypatch.setenv("RTN_CONV_TAIL_SLOTS", str(slots))
+    flags = L.CONV_RELU | (L.CONV_RES_SAME if res == "same" else 0) | (L.CONV_RES_UPSAMPLE if res == "up" else 0)
+    pad = "same" if k == 3 else 0
+    gots, wants, ld, n = run_case(pkg, handle, dtype, levels, cin, cout, k, 1, pad, flags, res, B=B, seed=77)
+    check(gots, wants, ld, n, dtype)
+    monkeypatch.setenv("RTN_CONV_TAIL", "0")                      # and the same layer without the split
+    gots0, _, _, _ = run_case(pkg, handle, dtype, levels, cin, cout, k, 1, pad, flags, res, B=B, seed=77)
+    for a, b in zip(gots, gots0):
+        assert float((a - b).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(b.abs().max()))
+        assert not torch.equal(a, b) or dtype == "bf16"      # f32: the split changes the summation order somewhere
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cout,sig", [(36, False), (9, True), (18, True)])
 def test_head_output_concat(pkg, handle, dtype, cout, sig):
