@@ -19,6 +19,7 @@ import ctypes as C
 import math
 
 import numpy as np
+import os
 import torch
 
 from . import _lib as L
@@ -41,6 +42,8 @@ class Trainer:
         self.bplans = {}
         self._init_params()
         self.bucketer = None
+        self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on a side HIP stream
+        self._wg_stream = None
         if self.pg is not None:
             segs = [(name, lo["woff"], lo["woff"] + lo["rows"] * lo["K"]) for name, lo in self.eng.layout.items()]
             segs.append(("__biases__", self.NW, self.NW + self.NB))           # FPN/head biases: one last segment
@@ -345,15 +348,39 @@ class Trainer:
                                             reg.data_ptr(), self.alpha, self.gamma, self.sigma, norm.data_ptr(), 1,
                                             bp["d_cls"].data_ptr(), bp["d_reg"].data_ptr()))
         self.grad.zero_()
+        # Two lanes: the data-gradient chain (and its helpers) stays on the launch stream, the weight / bias gradients go to a
+        # side stream.  A weight gradient needs its layer's dY complete - every launch-stream op enqueued before its place in
+        # the list - and nothing on the launch stream later overwrites what it reads (one gradient buffer per tensor, no
+        # reuse), so one event per switch of lane is the whole dependency.  The two kernel families fill each other's
+        # partly filled rounds of workgroups and atomics tails.
+        main = torch.cuda.current_stream(eng.device)
+        lane = self.wgrad_lane
+        if lane and self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=eng.device)
+            self._wg_ev, self._wg_done = torch.cuda.Event(), torch.cuda.Event()
+        side, dirty = self._wg_stream, True
         for b in bp["bops"]:
             kind = b[0]
+            on_side = lane and kind in ("wgrad", "bgrad")
+            if on_side:
+                if dirty:
+                    self._wg_ev.record(main)
+                    side.wait_event(self._wg_ev)
+                    dirty = False
+                h.set_stream(side.cuda_stream)
+            else:
+                dirty = True
             if kind == "wgrad":
                 if b[4] is not None:
                     h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], bp["ws"].data_ptr(), bp["ws"].numel()))
                 else:
                     h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
-                    self.bucketer.layer_done(b[3])
+                    if on_side:
+                        with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream
+                            self.bucketer.layer_done(b[3])
+                    else:
+                        self.bucketer.layer_done(b[3])
             elif kind == "dgrad":
                 h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
             elif kind == "bgrad":
@@ -372,6 +399,11 @@ class Trainer:
                                                             Bn, Hi, Wi, Cc, 1))
             else:
                 raise RuntimeError(kind)
+            if on_side:
+                h.set_stream(main.cuda_stream)
+        if lane:
+            self._wg_done.record(side)
+            main.wait_event(self._wg_done)
         return self.loss_sums
 
     def optimizer_step(self, lr=None):
