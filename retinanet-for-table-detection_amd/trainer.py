@@ -32,6 +32,7 @@ def _ceil128(v):
 
 
 class Trainer:
+    WG_LANES = 3          # side streams a weight gradient may go to (each has its own row-info workspace)
     def __init__(self, engine, lr=1e-4, clipnorm=0.001, beta1=0.9, beta2=0.999, eps=1e-7, alpha=0.25, gamma=2.0, sigma=3.0,
                  process_group=None):
         self.eng = engine
@@ -42,7 +43,8 @@ class Trainer:
         self.bplans = {}
         self._init_params()
         self.bucketer = None
-        self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on a side HIP stream
+        self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on side HIP streams
+        self.wgrad_lanes = max(1, min(self.WG_LANES, int(os.environ.get("RTN_WGRAD_LANES", "3"))))
         self._wg_stream = None
         if self.pg is not None:
             segs = [(name, lo["woff"], lo["woff"] + lo["rows"] * lo["K"]) for name, lo in self.eng.layout.items()]
@@ -317,7 +319,8 @@ class Trainer:
                 gstate[tid(x)] = "buf"
         ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
-        bp = {"bops": bops, "keep": keep, "ws": ws, "d_reg": d_reg, "d_cls": d_cls, "loss_ws": loss_ws, "plan": plan}
+        bp = {"bops": bops, "keep": keep, "ws": ws, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
+              "d_reg": d_reg, "d_cls": d_cls, "loss_ws": loss_ws, "plan": plan}
         self.bplans[key] = bp
         return bp
 
@@ -355,26 +358,34 @@ class Trainer:
         # partly filled rounds of workgroups and atomics tails.
         main = torch.cuda.current_stream(eng.device)
         lane = self.wgrad_lane
+        nl = (1 if self.bucketer is not None else self.wgrad_lanes) if lane else 0      # DP: one lane, so a bucket's event covers its layers
         if lane and self._wg_stream is None:
-            self._wg_stream = torch.cuda.Stream(device=eng.device)
-            self._wg_ev, self._wg_done = torch.cuda.Event(), torch.cuda.Event()
-        side, dirty = self._wg_stream, True
+            self._wg_stream = [torch.cuda.Stream(device=eng.device) for _ in range(self.WG_LANES)]
+            self._wg_ev = torch.cuda.Event()
+            self._wg_done = [torch.cuda.Event() for _ in range(self.WG_LANES)]
+        synced = [False] * max(nl, 1)                 # lane k has waited for everything on the launch stream so far
+        turn = 0
+        side, ws = None, bp["ws"]
         for b in bp["bops"]:
             kind = b[0]
             on_side = lane and kind in ("wgrad", "bgrad")
-            if on_side:
-                if dirty:
-                    self._wg_ev.record(main)
+            if on_side:                               # weight gradients are independent of each other: round-robin over the lanes
+                k = turn % nl
+                turn += 1
+                side, ws = self._wg_stream[k], bp["ws_lanes"][k]
+                if not synced[k]:
+                    if not any(synced):
+                        self._wg_ev.record(main)
                     side.wait_event(self._wg_ev)
-                    dirty = False
+                    synced[k] = True
                 h.set_stream(side.cuda_stream)
             else:
-                dirty = True
+                synced = [False] * max(nl, 1)
             if kind == "wgrad":
                 if b[4] is not None:
-                    h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], bp["ws"].data_ptr(), bp["ws"].numel()))
+                    h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], ws.data_ptr(), ws.numel()))
                 else:
-                    h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
+                    h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), ws.data_ptr(), ws.numel()))
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
                     if on_side:
                         with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream
@@ -401,9 +412,9 @@ class Trainer:
                 raise RuntimeError(kind)
             if on_side:
                 h.set_stream(main.cuda_stream)
-        if lane:
-            self._wg_done.record(side)
-            main.wait_event(self._wg_done)
+        for k in range(nl):
+            self._wg_done[k].record(self._wg_stream[k])
+            main.wait_event(self._wg_done[k])
         return self.loss_sums
 
     def optimizer_step(self, lr=None):
