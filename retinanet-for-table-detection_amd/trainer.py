@@ -320,11 +320,93 @@ class Trainer:
         ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
         bp = {"bops": bops, "keep": keep, "ws": ws, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
-              "d_reg": d_reg, "d_cls": d_cls, "loss_ws": loss_ws, "plan": plan}
+              "d_reg": d_reg, "d_cls": d_cls, "dyp_cls": dyp_cls, "loss_ws": loss_ws, "plan": plan}
         self.bplans[key] = bp
         return bp
 
     # ------------------------------------------------------------------ step
+    # ------------------------------------------------------------------ backward lanes
+    @staticmethod
+    def _bop_io(b):
+        """(pointers read, pointers written) of a backward op (accumulating outputs are both)."""
+        kind = b[0]
+        if kind == "padcast":
+            return [b[1].data_ptr()], [b[2].data_ptr()]
+        if kind == "zins":
+            return [b[1].data_ptr()], [b[2].data_ptr()]
+        if kind == "upbwd":
+            return [b[1].data_ptr()] + ([b[2].data_ptr()] if b[4] else []), [b[2].data_ptr()]
+        if kind == "poolbwd":
+            return [b[1].data_ptr(), b[2].data_ptr(), b[5].data_ptr()], [b[3].data_ptr()]
+        d = b[1]
+        if kind == "wgrad":
+            reads = [p_ for i in range(d.ngroups) for p_ in (d.g[i].in_, d.g[i].out)]
+            return reads, [b[2].data_ptr()] + ([b[4].data_ptr()] if b[4] is not None else [])
+        if kind == "dgrad":
+            reads, writes = [], []
+            for i in range(d.ngroups):
+                g = d.g[i]
+                reads.append(g.in_)
+                if d.flags & L.CONV_RELU_MASK:
+                    reads.append(g.mask)
+                if d.flags & (L.CONV_RES_SAME | L.CONV_RES_UPSAMPLE):
+                    reads.append(g.res)
+                writes.append(g.out)
+            return reads, writes
+        raise RuntimeError(kind)
+
+    def _bschedule(self, bops, nwg, dyp_cls):
+        """Lane of every backward op and the cross-lane events it must wait for.  Lane 0: the data-gradient chain; lanes
+        1..nwg: weight / bias gradients (independent of each other: round-robin); lane nwg+1: the data gradients of the
+        classification tower, which only meet the rest of the graph where the pyramid gradients are summed.  Hazards are
+        tracked per buffer: read-after-write, write-after-write and write-after-read (gradient buffers are accumulated in
+        place by several ops)."""
+        lanes, turn = [], 0
+        extra = os.environ.get("RTN_BWD_EXTRA_LANE", "0") != "0"
+        for b in bops:
+            if b[0] in ("wgrad", "bgrad"):
+                lanes.append(1 + turn % nwg)
+                turn += 1
+            elif (b[0] == "dgrad" and str(b[2]).startswith("pyramid_classification")) or (b[0] == "padcast" and b[2] is dyp_cls):
+                lanes.append(nwg + 1)
+            elif extra and b[0] == "dgrad" and (str(b[2]).endswith("_branch1") or str(b[2]) in ("P6", "P7", "P5", "P4")):
+                lanes.append(nwg + 2)
+            else:
+                lanes.append(0)
+        writer, readers, waits = {}, {}, []
+        for i, b in enumerate(bops):
+            reads, writes = self._bop_io(b)
+            reads = [p_ for p_ in reads if p_]
+            writes = [p_ for p_ in writes if p_]
+            deps = set()
+            for ptr in reads:
+                j = writer.get(ptr)
+                if j is not None and lanes[j] != lanes[i]:
+                    deps.add(j)
+            for ptr in writes:
+                j = writer.get(ptr)
+                if j is not None and lanes[j] != lanes[i]:
+                    deps.add(j)
+                for j in readers.get(ptr, ()):
+                    if lanes[j] != lanes[i]:
+                        deps.add(j)
+            latest = {}
+            for j in deps:
+                latest[lanes[j]] = max(latest.get(lanes[j], -1), j)
+            waits.append(sorted(latest.values()))
+            for ptr in reads:
+                readers.setdefault(ptr, []).append(i)
+            for ptr in writes:
+                writer[ptr] = i
+                readers[ptr] = []
+        events = set(j for w in waits for j in w)
+        last = {}
+        for i, ln in enumerate(lanes):
+            last[ln] = i
+        joins = sorted(i for ln, i in last.items() if ln != 0)
+        events.update(joins)
+        return {"lanes": lanes, "waits": waits, "events": events, "joins": joins, "nlanes": max(lanes) + 1}
+
     def forward_backward(self, images, regression_batch, labels_batch):
         """Forward, loss and backward; leaves dL/dparams in self.grad (flat f32) and returns the device tensor
         loss_sums = [sum focal terms, sum smooth-L1 terms, #positives (labels), #positives (regression)] of THIS rank."""
@@ -351,36 +433,40 @@ class Trainer:
                                             reg.data_ptr(), self.alpha, self.gamma, self.sigma, norm.data_ptr(), 1,
                                             bp["d_cls"].data_ptr(), bp["d_reg"].data_ptr()))
         self.grad.zero_()
-        # Two lanes: the data-gradient chain (and its helpers) stays on the launch stream, the weight / bias gradients go to a
-        # side stream.  A weight gradient needs its layer's dY complete - every launch-stream op enqueued before its place in
-        # the list - and nothing on the launch stream later overwrites what it reads (one gradient buffer per tensor, no
-        # reuse), so one event per switch of lane is the whole dependency.  The two kernel families fill each other's
-        # partly filled rounds of workgroups and atomics tails.
+        # Lanes (see _bschedule): data-gradient chain on the launch stream; weight / bias gradients round-robin over side streams;
+        # the classification tower's data gradients on one more.  Events follow the per-buffer hazards.
         main = torch.cuda.current_stream(eng.device)
-        lane = self.wgrad_lane
-        nl = (1 if self.bucketer is not None else self.wgrad_lanes) if lane else 0      # DP: one lane, so a bucket's event covers its layers
-        if lane and self._wg_stream is None:
-            self._wg_stream = [torch.cuda.Stream(device=eng.device) for _ in range(self.WG_LANES)]
-            self._wg_ev = torch.cuda.Event()
-            self._wg_done = [torch.cuda.Event() for _ in range(self.WG_LANES)]
-        synced = [False] * max(nl, 1)                 # lane k has waited for everything on the launch stream so far
-        turn = 0
-        side, ws = None, bp["ws"]
-        for b in bp["bops"]:
+        lane_on = self.wgrad_lane
+        nwg = 1 if self.bucketer is not None else self.wgrad_lanes        # DP: one lane, so a bucket's event covers its layers
+        if lane_on:
+            key = ("bsched", nwg)
+            if key not in bp:
+                sch = self._bschedule(bp["bops"], nwg, bp["dyp_cls"])
+                sch["ev"] = {i: torch.cuda.Event() for i in sch["events"]}
+                bp[key] = sch
+            sch = bp[key]
+            if self._wg_stream is None or len(self._wg_stream) < sch["nlanes"] - 1:
+                self._wg_stream = [torch.cuda.Stream(device=eng.device) for _ in range(self.WG_LANES + 2)]
+                self._wg_ev = torch.cuda.Event()
+            streams = [main] + self._wg_stream[:sch["nlanes"] - 1]
+            self._wg_ev.record(main)                      # side lanes start behind the loss backward and the gradient reset
+            for st in streams[1:]:
+                st.wait_event(self._wg_ev)
+        ws = bp["ws"]
+        for bi, b in enumerate(bp["bops"]):
             kind = b[0]
-            on_side = lane and kind in ("wgrad", "bgrad")
-            if on_side:                               # weight gradients are independent of each other: round-robin over the lanes
-                k = turn % nl
-                turn += 1
-                side, ws = self._wg_stream[k], bp["ws_lanes"][k]
-                if not synced[k]:
-                    if not any(synced):
-                        self._wg_ev.record(main)
-                    side.wait_event(self._wg_ev)
-                    synced[k] = True
-                h.set_stream(side.cuda_stream)
-            else:
-                synced = [False] * max(nl, 1)
+            on_side = False
+            if lane_on:
+                ln = sch["lanes"][bi]
+                st = streams[ln]
+                for j in sch["waits"][bi]:
+                    st.wait_event(sch["ev"][j])
+                on_side = ln != 0
+                if on_side:
+                    side = st
+                    h.set_stream(st.cuda_stream)
+                    if 1 <= ln <= nwg:
+                        ws = bp["ws_lanes"][ln - 1]
             if kind == "wgrad":
                 if b[4] is not None:
                     h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], ws.data_ptr(), ws.numel()))
@@ -410,11 +496,14 @@ class Trainer:
                                                             Bn, Hi, Wi, Cc, 1))
             else:
                 raise RuntimeError(kind)
-            if on_side:
-                h.set_stream(main.cuda_stream)
-        for k in range(nl):
-            self._wg_done[k].record(self._wg_stream[k])
-            main.wait_event(self._wg_done[k])
+            if lane_on:
+                if bi in sch["ev"]:
+                    sch["ev"][bi].record(st)
+                if on_side:
+                    h.set_stream(main.cuda_stream)
+        if lane_on:
+            for j in sch["joins"]:
+                main.wait_event(sch["ev"][j])
         return self.loss_sums
 
     def optimizer_step(self, lr=None):
