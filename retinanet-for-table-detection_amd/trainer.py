@@ -375,7 +375,7 @@ class Trainer:
                 lanes.append(0)
         writer, readers, waits = {}, {}, []
         for i, b in enumerate(bops):
-            reads, writes = self._bop_io(b)
+            reads, writes = Trainer._bop_io(b)
             reads = [p_ for p_ in reads if p_]
             writes = [p_ for p_ in writes if p_]
             deps = set()
