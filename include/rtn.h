@@ -156,6 +156,10 @@ int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_con
 int rtn_conv2d_dgrad(rtn_handle_t h, const rtn_conv_desc_t* d);
 int rtn_pack_dgrad_weights(rtn_handle_t h, const void* w_fwd, void* w_dgrad, int dtype, int N, int w_rows_fwd,
                            int KH, int KW, int Cin, int Cout_run, int w_rows_dgrad);
+/* Every layer's dgrad weights in ONE launch (after an optimizer step rewrote the forward weights).  table_dev: device array of
+ * nlayers x 10 int64 {w_fwd pointer, w_dgrad pointer, N, KH, KW, Cin, Cout_run, w_rows_dgrad, first flat element of the layer in
+ * the concatenation of all w_dgrad arrays, 0}; total_elems = sum of w_rows_dgrad * KH*KW*Cout_run. */
+int rtn_pack_dgrad_weights_multi(rtn_handle_t h, const int64_t* table_dev, int nlayers, int64_t total_elems, int dtype);
 
 /* Weight gradient (Conv2DBackpropFilter).  `d` describes the FORWARD convolution with two re-interpretations:
  * g[i].out / out_elems / out_img_stride / out_off and out_ld describe dY (same dtype as `in`; N and out_ld must span whole
@@ -167,6 +171,11 @@ int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* 
 /* the same with BiasAddGrad fused: db[0..db_n) += sum over pixels of dY[:, n] (db_n <= N) */
 int rtn_conv2d_wgrad_bias(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace,
                           size_t workspace_bytes);
+/* The row-info table of a weight-gradient launch depends only on the descriptor (geometry, strides, dY / X offsets): build it
+ * once per layer with rtn_conv2d_wgrad_rowinfo and reuse it with rtn_conv2d_wgrad_prepared (db may be NULL). */
+int rtn_conv2d_wgrad_rowinfo(rtn_handle_t h, const rtn_conv_desc_t* d, void* workspace, size_t workspace_bytes);
+int rtn_conv2d_wgrad_prepared(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, const void* workspace,
+                              size_t workspace_bytes);
 /* db[n] += sum over rows of dy[row][n]   (rows x N matrix with leading dimension ld, dtype bf16/f32) */
 int rtn_bias_grad(rtn_handle_t h, const void* dy, int dtype, int64_t rows, int N, int64_t ld, float* db);
 /* out[r][0..cout) = cast(in[r][0..cin)), zero beyond cin */

@@ -85,9 +85,12 @@ SIGNATURES = {
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "rtn_pack_dgrad_weights_multi": (_I, [_P, _P, _I, _I64, _I]),
     "rtn_conv2d_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),
     "rtn_conv2d_wgrad": (_I, [_P, C.POINTER(ConvDesc), _P, _P, _SZ]),
     "rtn_conv2d_wgrad_bias": (_I, [_P, C.POINTER(ConvDesc), _P, _P, _I, _P, _SZ]),
+    "rtn_conv2d_wgrad_rowinfo": (_I, [_P, C.POINTER(ConvDesc), _P, _SZ]),
+    "rtn_conv2d_wgrad_prepared": (_I, [_P, C.POINTER(ConvDesc), _P, _P, _I, _P, _SZ]),
     "rtn_bias_grad": (_I, [_P, _P, _I, _I64, _I, _I64, _P]),
     "rtn_pad_cast_rows": (_I, [_P, _P, _P, _I, _I64, _I, _I]),
     "rtn_zero_insert2": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),

@@ -962,10 +962,21 @@ extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
     return (size_t)tiles * 64 * sizeof(uint4);
 }
 
-static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);
+static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes,
+                        int mode = 0 /* 0: build the row-info table and run; 1: build it only; 2: run on a table built earlier */);
 
 extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes) {
     return wgrad_launch(h, d, dW, nullptr, 0, workspace, workspace_bytes);
+}
+
+/* The per-pixel row-info table alone (workspace), and the weight gradient on a table built earlier for the SAME descriptor. */
+extern "C" int rtn_conv2d_wgrad_rowinfo(rtn_handle_t h, const rtn_conv_desc_t* d, void* workspace, size_t workspace_bytes) {
+    return wgrad_launch(h, d, nullptr, nullptr, 0, workspace, workspace_bytes, 1);
+}
+extern "C" int rtn_conv2d_wgrad_prepared(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, const void* workspace,
+                                         size_t workspace_bytes) {
+    if (h && db && (db_n < 1 || (d && db_n > d->N))) return rtn_fail(h, RTN_EINVAL, "wgrad_prepared: bad db_n");
+    return wgrad_launch(h, d, dW, db, db ? db_n : 0, const_cast<void*>(workspace), workspace_bytes, 2);
 }
 
 /* wgrad with the bias gradient fused: db[0..db_n) += column sums of dY (BiasAddGrad) */
@@ -975,9 +986,9 @@ extern "C" int rtn_conv2d_wgrad_bias(rtn_handle_t h, const rtn_conv_desc_t* d, f
     return wgrad_launch(h, d, dW, db, db_n, workspace, workspace_bytes);
 }
 
-static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes) {
+static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes, int mode) {
     if (!h) return RTN_EINVAL;
-    if (!d || !dW || !workspace) return rtn_fail(h, RTN_EINVAL, "wgrad: null argument");
+    if (!d || (!dW && mode != 1) || !workspace) return rtn_fail(h, RTN_EINVAL, "wgrad: null argument");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "wgrad: bad dtype");
     const int es = rtn_dtype_size(d->dtype);
     if (d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS || d->batch < 1 || d->N < 1) return rtn_fail(h, RTN_EINVAL, "wgrad: bad group/batch/N");
@@ -1069,9 +1080,12 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.tiles_per_split = (int)((tiles + nsplit - 1) / nsplit);
     nsplit = (tiles + p.tiles_per_split - 1) / p.tiles_per_split;
 
-    if (es == 2) hipLaunchKernelGGL((wgrad_rowinfo_kernel<2>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
-    else         hipLaunchKernelGGL((wgrad_rowinfo_kernel<4>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
-    RTN_CHECK_LAUNCH(h, "wgrad_rowinfo_kernel");
+    if (mode != 2) {         // the table depends on the layer's geometry and the dY / X base offsets only: a caller may build it once
+        if (es == 2) hipLaunchKernelGGL((wgrad_rowinfo_kernel<2>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
+        else         hipLaunchKernelGGL((wgrad_rowinfo_kernel<4>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
+        RTN_CHECK_LAUNCH(h, "wgrad_rowinfo_kernel");
+        if (mode == 1) return RTN_OK;
+    }
     if (xcd_map && (nsplit & 7)) {              // the recomputed split count must stay a multiple of 8 for the XCD map
         const long long up = (nsplit + 7) & ~7ll;    // extra splits are empty (tlo >= thi) and return at once
         nsplit = up;

@@ -1579,7 +1579,46 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ w
         wd[i] = v;
     }
 }
+// All layers in one launch.  table[l] = {src, dst, N, KH, KW, Cin, Crun, rows_d, first flat element of layer l, -}; the flat
+// element index is searched in the prefix column (binary search, ~7 steps for a ResNet-50 RetinaNet).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const long long* __restrict__ table, int nlayers, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nlayers - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 10 + 8] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long long* e = table + lo * 10;
+        const T* wf = reinterpret_cast<const T*>(e[0]);
+        T* wd = reinterpret_cast<T*>(e[1]);
+        const int N = (int)e[2], KH = (int)e[3], KW = (int)e[4], Cin = (int)e[5], Crun = (int)e[6];
+        const long long j = i - e[8];
+        const long long Kd = (long long)KH * KW * Crun, Kf = (long long)KH * KW * Cin;
+        const int c = (int)(j / Kd);
+        const int r = (int)(j - (long long)c * Kd);
+        const int tap = r / Crun, n = r - tap * Crun;
+        const int khd = tap / KW, kwd = tap - khd * KW;
+        T v = T(0);
+        if (c < Cin && n < N) v = wf[(long long)n * Kf + ((long long)(KH - 1 - khd) * KW + (KW - 1 - kwd)) * Cin + c];
+        wd[j] = v;
+    }
+}
 }  // namespace
+
+extern "C" int rtn_pack_dgrad_weights_multi(rtn_handle_t h, const int64_t* table_dev, int nlayers, int64_t total_elems, int dtype) {
+    if (!h) return RTN_EINVAL;
+    if (!table_dev || nlayers < 1 || total_elems < 1) return rtn_fail(h, RTN_EINVAL, "pack_dgrad_multi: bad argument");
+    if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "pack_dgrad_multi: bad dtype");
+    long long g = (total_elems + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (dtype == RTN_BF16)
+        hipLaunchKernelGGL((pack_dgrad_multi_kernel<unsigned short>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers, (long long)total_elems);
+    else
+        hipLaunchKernelGGL((pack_dgrad_multi_kernel<float>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers, (long long)total_elems);
+    RTN_CHECK_LAUNCH(h, "pack_dgrad_multi_kernel");
+    return RTN_OK;
+}
 
 extern "C" int rtn_pack_dgrad_weights(rtn_handle_t h, const void* w_fwd, void* w_dgrad, int dtype, int N, int w_rows_fwd, int KH,
                                       int KW, int Cin, int Cout_run, int w_rows_dgrad) {

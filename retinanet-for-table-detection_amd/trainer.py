@@ -98,6 +98,7 @@ class Trainer:
                 continue
             crun = self._dy_channels(name)
             self.wd[name] = torch.empty(_ceil128(lo["cin"]), lo["kh"] * lo["kw"] * crun, dtype=eng.tdt, device=dev)
+        self._pack_table = None
         self._repack_dgrad()
 
     def _dy_channels(self, name):
@@ -111,13 +112,19 @@ class Trainer:
         return cout
 
     def _repack_dgrad(self):
+        """Every layer's dgrad weights from the (rewritten) forward weights, one launch: rtn_pack_dgrad_weights_multi."""
         eng = self.eng
         eng._bind_stream()
-        for name, wd in self.wd.items():
-            lo = eng.layout[name]
-            wf = eng.w[name][0]
-            eng.h.check(L.lib.rtn_pack_dgrad_weights(eng.h.raw, wf.data_ptr(), wd.data_ptr(), eng.rdt, lo["cout"], lo["rows"],
-                                                     lo["kh"], lo["kw"], lo["cin"], self._dy_channels(name), wd.shape[0]))
+        if self._pack_table is None or self._pack_table[3] != eng.wflat.data_ptr():      # (re)built when the weights were reallocated
+            rows, total = [], 0
+            for name, wd in self.wd.items():
+                lo = eng.layout[name]
+                rows.append([eng.w[name][0].data_ptr(), wd.data_ptr(), lo["cout"], lo["kh"], lo["kw"], lo["cin"], self._dy_channels(name),
+                             wd.shape[0], total, 0])
+                total += wd.numel()
+            self._pack_table = (torch.tensor(rows, dtype=torch.int64, device=eng.device), len(rows), total, eng.wflat.data_ptr())
+        table, n, total, _ = self._pack_table
+        eng.h.check(L.lib.rtn_pack_dgrad_weights_multi(eng.h.raw, table.data_ptr(), n, total, eng.rdt))
 
     def grad_views(self, name):
         """(dW [rows][K] f32, db [rows] f32) views of the flat gradient buffer for one layer."""
@@ -320,7 +327,7 @@ class Trainer:
         ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
         bp = {"bops": bops, "keep": keep, "ws": ws, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
-              "d_reg": d_reg, "d_cls": d_cls, "dyp_cls": dyp_cls, "loss_ws": loss_ws, "plan": plan}
+              "d_reg": d_reg, "d_cls": d_cls, "dyp_cls": dyp_cls, "loss_ws": loss_ws, "plan": plan, "rowinfo": {}}
         self.bplans[key] = bp
         return bp
 
@@ -468,10 +475,13 @@ class Trainer:
                     if 1 <= ln <= nwg:
                         ws = bp["ws_lanes"][ln - 1]
             if kind == "wgrad":
-                if b[4] is not None:
-                    h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], ws.data_ptr(), ws.numel()))
-                else:
-                    h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), ws.data_ptr(), ws.numel()))
+                tab = bp["rowinfo"].get(bi)
+                if tab is None:                       # the row-info table depends on the descriptor only: built once per layer
+                    tab = torch.empty(L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(b[1])), dtype=torch.uint8, device=eng.device)
+                    h.check(lib.rtn_conv2d_wgrad_rowinfo(h.raw, C.byref(b[1]), tab.data_ptr(), tab.numel()))
+                    bp["rowinfo"][bi] = tab
+                h.check(lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr() if b[4] is not None else None,
+                                                      b[5] if b[4] is not None else 0, tab.data_ptr(), tab.numel()))
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
                     if on_side:
                         with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream

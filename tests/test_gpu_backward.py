@@ -365,3 +365,28 @@ def test_wgrad_dma_grouped_levels_match_the_small_kernel(pkg, handle, monkeypatc
         assert scale > 1.0 and float((a - b).abs().max()) <= 1e-4 * scale
     want_db = dy.float().cpu().double().sum(dim=(0, 1))
     assert float((got["2"][1] - want_db).abs().max()) <= 1e-4 * float(want_db.abs().max())
+
+
+def test_pack_dgrad_multi_equals_per_layer_pack(pkg, handle):
+    """rtn_pack_dgrad_weights_multi (every layer in one launch, table-driven) must write the bits of rtn_pack_dgrad_weights."""
+    L = pkg._lib
+    tdt, code = DT["bf16"]
+    g = torch.Generator().manual_seed(3)
+    layers = [(64, 3, 3, 64, 64), (256, 1, 1, 64, 256), (36, 3, 3, 256, 64), (128, 1, 1, 256, 128)]     # cout, kh, kw, cin, dY channels
+    rows, total, keep, want = [], 0, [], []
+    for cout, kh, kw, cin, crun in layers:
+        rows_f = -(-cout // 128) * 128
+        wf = torch.randn(rows_f, kh * kw * cin, generator=g).to(tdt).to(DEV).contiguous()
+        rows_d = -(-cin // 128) * 128
+        wd = torch.full((rows_d, kh * kw * crun), 7.0, dtype=tdt, device=DEV)
+        ref = torch.empty_like(wd)
+        handle.check(L.lib.rtn_pack_dgrad_weights(handle.raw, wf.data_ptr(), ref.data_ptr(), code, cout, rows_f, kh, kw, cin, crun, rows_d))
+        rows.append([wf.data_ptr(), wd.data_ptr(), cout, kh, kw, cin, crun, rows_d, total, 0])
+        total += wd.numel()
+        keep += [wf, wd]
+        want.append((wd, ref))
+    table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    handle.check(L.lib.rtn_pack_dgrad_weights_multi(handle.raw, table.data_ptr(), len(rows), total, code))
+    torch.cuda.synchronize()
+    for wd, ref in want:
+        assert torch.equal(wd, ref)
