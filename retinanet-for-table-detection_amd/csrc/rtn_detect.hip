@@ -458,17 +458,17 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(const DevAnchorCfg c, int K,
                 if (cidx + 1 < nc && kept < max_det) {           // rows of the newly kept candidates -> removed words
                     u64 km = keep, acc = 0;
                     const u64* Mc = M + (long long)cidx * 64 * (CAP / 64) + lane;
-                    while (km != 0) {                            // four independent row loads in flight
-                        int jj[4];
+                    while (km != 0) {                            // eight independent row loads in flight (one L2 round trip per batch)
+                        int jj[8];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < 8; ++q) {
                             jj[q] = km != 0 ? __ffsll((long long)km) - 1 : -1;
                             if (km != 0) km &= km - 1;
                         }
-                        u64 w[4];
+                        u64 w[8];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = jj[q] >= 0 ? Mc[(long long)jj[q] * (CAP / 64)] : 0ull;
-                        acc |= (w[0] | w[1]) | (w[2] | w[3]);
+                        for (int q = 0; q < 8; ++q) w[q] = jj[q] >= 0 ? Mc[(long long)jj[q] * (CAP / 64)] : 0ull;
+                        acc |= ((w[0] | w[1]) | (w[2] | w[3])) | ((w[4] | w[5]) | (w[6] | w[7]));
                     }
                     rem |= acc;
                 }
