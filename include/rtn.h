@@ -351,6 +351,15 @@ int rtn_distance_transform3(rtn_handle_t h, const uint8_t* binary, int B, int H,
 int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, int H, int W, int C, double scale, void* dst, int dst_dtype,
                      int Ho, int Wo, int64_t dst_row_stride);
 
+/* transform.apply_transform (model/transform.py:343-362) = cv2.warpAffine(image, matrix[:2], dsize = image size, flags, borderMode,
+ * borderValue) of one uint8 HxWxC page (C <= 4), as Generator.random_transform_group_entry calls it (csv_generator.py:248-265).
+ *   inv_map6 (host, 6 doubles, row-major 2x3): the destination->source map, i.e. the matrix already inverted the way warpAffine
+ *     inverts it when WARP_INVERSE_MAP is absent;  interpolation 0 = INTER_NEAREST, 1 = INTER_LINEAR (TransformParameters
+ *     default, model/transform.py:289-299);  border_mode 0 constant / 1 replicate ('nearest', the default) / 2 reflect101 / 3 wrap
+ *     (model/transform.py:301-309);  cval4 (host, may be NULL = zeros): per-channel fill for border_mode 0. */
+int rtn_warp_affine_u8(rtn_handle_t h, const uint8_t* src, int H, int W, int C, const double* inv_map6, int interpolation,
+                       int border_mode, const uint8_t* cval4, uint8_t* dst);
+
 /* The graph layers as separate calls (model/layers.py): FilterDetections on explicit boxes, RegressBoxes, ClipBoxes,
  * UpsampleLike; and utils.preprocess_image (model/utils.py:19-47; mode 0 'tf', 1 'caffe', 2 'custom_tf'). */
 int rtn_filter_detections(rtn_handle_t h, int B, int64_t N, int num_classes, const float* in_boxes, const float* classification,

@@ -122,6 +122,7 @@ SIGNATURES = {
     "rtn_preprocess_dt3": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _SZ]),
     "rtn_distance_transform3": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ]),
     "rtn_resize_cubic": (_I, [_P, _P, _I, _I, _I, _I, _D, _P, _I, _I, _I, _I64]),
+    "rtn_warp_affine_u8": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
     "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),
     "rtn_retina_loss_bwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P]),

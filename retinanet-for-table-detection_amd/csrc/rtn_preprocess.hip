@@ -348,3 +348,89 @@ extern "C" int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, 
     RTN_CHECK_LAUNCH(h, "resize_cubic_kernel");
     return RTN_OK;
 }
+
+// ---- transform.apply_transform (model/transform.py:343-362): cv2.warpAffine of a uint8 HxWxC page ---------------------------
+// The host passes the INVERSE map (destination -> source), inverted in double the way warpAffine does when WARP_INVERSE_MAP is
+// not set.  Coordinates are OpenCV's fixed point: AB_BITS = 10 fractional bits for the products, INTER_BITS = 5 for the sampling
+// position (1/32 pixel); the bilinear weights are the 15-bit table entries 32*(32-a)*(32-b) (short-saturated), the result
+// (sum + 2^14) >> 15.  Integer work from the two products on: bit-exact against oracle/ref_generator.py.
+struct WarpParams {
+    double m[6];
+    int H, W, C, interp, border;
+    unsigned char cval[4];
+};
+
+__device__ __forceinline__ int border_index(int p, int len, int mode) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (mode == 1) return p < 0 ? 0 : len - 1;                       // BORDER_REPLICATE
+    if (mode == 2) {                                                 // BORDER_REFLECT_101
+        if (len == 1) return 0;
+        do { p = p < 0 ? -p : 2 * len - 2 - p; } while ((unsigned)p >= (unsigned)len);
+        return p;
+    }
+    if (mode == 3) {                                                 // BORDER_WRAP
+        if (p < 0) p -= ((p - len + 1) / len) * len;
+        if (p >= len) p %= len;
+        return p;
+    }
+    return -1;                                                       // BORDER_CONSTANT
+}
+
+__global__ __launch_bounds__(256) void warp_affine_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, WarpParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const int round_delta = p.interp ? 16 : 512;
+    const int X0 = __double2int_rn((p.m[1] * (double)y + p.m[2]) * 1024.0) + round_delta;
+    const int Y0 = __double2int_rn((p.m[4] * (double)y + p.m[5]) * 1024.0) + round_delta;
+    const int ax = __double2int_rn(p.m[0] * (double)x * 1024.0), bx = __double2int_rn(p.m[3] * (double)x * 1024.0);
+    const int sh = p.interp ? 5 : 10;
+    int X = (X0 + ax) >> sh, Y = (Y0 + bx) >> sh;
+    int sx, sy, fa = 0, fb = 0;
+    if (p.interp) { sx = X >> 5; sy = Y >> 5; fa = X & 31; fb = Y & 31; }
+    else { sx = X; sy = Y; }
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    unsigned char* o = dst + ((long long)y * p.W + x) * p.C;
+    if (!p.interp) {
+        const int ix = border_index(sx, p.W, p.border), iy = border_index(sy, p.H, p.border);
+        for (int c = 0; c < p.C; ++c) o[c] = (ix < 0 || iy < 0) ? p.cval[c] : src[((long long)iy * p.W + ix) * p.C + c];
+        return;
+    }
+    if (p.border == 0 && (sx >= p.W || sx + 1 < 0 || sy >= p.H || sy + 1 < 0)) {
+        for (int c = 0; c < p.C; ++c) o[c] = p.cval[c];
+        return;
+    }
+    int w[4] = {32 * (32 - fa) * (32 - fb), 32 * fa * (32 - fb), 32 * (32 - fa) * fb, 32 * fa * fb};
+    if (w[0] > 32767) w[0] = 32767;
+    const int x0 = border_index(sx, p.W, p.border), x1 = border_index(sx + 1, p.W, p.border);
+    const int y0 = border_index(sy, p.H, p.border), y1 = border_index(sy + 1, p.H, p.border);
+    for (int c = 0; c < p.C; ++c) {
+        const int cv = p.cval[c];
+        const int v00 = (x0 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x0) * p.C + c];
+        const int v01 = (x1 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x1) * p.C + c];
+        const int v10 = (x0 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x0) * p.C + c];
+        const int v11 = (x1 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x1) * p.C + c];
+        int r = (v00 * w[0] + v01 * w[1] + v10 * w[2] + v11 * w[3] + (1 << 14)) >> 15;
+        o[c] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+extern "C" int rtn_warp_affine_u8(rtn_handle_t h, const uint8_t* src, int H, int W, int C, const double* inv_map6, int interpolation,
+                                  int border_mode, const uint8_t* cval4, uint8_t* dst) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || !inv_map6 || H < 1 || W < 1 || C < 1 || C > 4) return rtn_fail(h, RTN_EINVAL, "warp_affine: bad argument");
+    if (H > 32767 || W > 32767) return rtn_fail(h, RTN_EINVAL, "warp_affine: image sides must be < 32768");
+    if (interpolation != 0 && interpolation != 1) return rtn_fail(h, RTN_EINVAL, "warp_affine: interpolation must be nearest (0) or linear (1)");
+    if (border_mode < 0 || border_mode > 3) return rtn_fail(h, RTN_EINVAL, "warp_affine: border mode must be constant/replicate/reflect101/wrap (0..3)");
+    if (src == dst) return rtn_fail(h, RTN_EINVAL, "warp_affine: in-place is not supported");
+    WarpParams p;
+    for (int i = 0; i < 6; ++i) {
+        if (!(inv_map6[i] == inv_map6[i]) || inv_map6[i] > 1e300 || inv_map6[i] < -1e300) return rtn_fail(h, RTN_EINVAL, "warp_affine: matrix entry %d is not finite", i);
+        p.m[i] = inv_map6[i];
+    }
+    p.H = H; p.W = W; p.C = C; p.interp = interpolation; p.border = border_mode;
+    for (int c = 0; c < 4; ++c) p.cval[c] = cval4 ? cval4[c] : 0;
+    hipLaunchKernelGGL(warp_affine_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, h->stream, src, dst, p);
+    RTN_CHECK_LAUNCH(h, "warp_affine_kernel");
+    return RTN_OK;
+}
