@@ -250,6 +250,68 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const void* __restric
     }
 }
 
+// The generator's case (uint8 BGR page, C = 3): one thread per OUTPUT PIXEL instead of per element, so the source coordinate and
+// the eight cubic weights are computed once for the three channels; x/127.5 - 1 comes from a 256-entry LDS table filled with the
+// very same two roundings; an interior pixel fetches each of its four source rows as three (unaligned) dwords = 4 px * 3 ch.
+// Per channel the sums run in the order of resize_cubic_kernel: bit-identical results.
+template <int DST_BF16>
+__global__ __launch_bounds__(256) void resize_cubic_u8c3_kernel(const unsigned char* __restrict__ src, int H, int W, double inv_scale,
+                                                                void* __restrict__ dst, int Ho, int Wo, long long dst_row_stride) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = __fsub_rn(__fdiv_rn((float)threadIdx.x, 127.5f), 1.0f);
+    __syncthreads();
+    const long long total = (long long)Ho * Wo;
+    const long long src_bytes = (long long)H * W * 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % Wo), dy = (int)(i / Wo);
+        const double fx = ((double)dx + 0.5) * inv_scale - 0.5, fy = ((double)dy + 0.5) * inv_scale - 0.5;
+        const int sx = (int)floor(fx), sy = (int)floor(fy);
+        float kx[4], ky[4];
+        cubic_coeffs((float)(fx - (double)sx), kx);
+        cubic_coeffs((float)(fy - (double)sy), ky);
+        const bool inside_x = sx >= 1 && sx + 2 < W;
+        float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int yy = sy - 1 + j;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            const long long rowb = (long long)yy * W * 3;
+            unsigned char t[12];
+            const long long at = rowb + (long long)(sx - 1) * 3;
+            if (inside_x && at + 12 <= src_bytes) {
+                unsigned int w3[3];
+                __builtin_memcpy(w3, src + at, 12);
+                __builtin_memcpy(t, w3, 12);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int xx = sx - 1 + k;
+                    xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) t[k * 3 + c] = src[rowb + (long long)xx * 3 + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = acc + lut[t[k * 3 + c]] * kx[k];
+                o[c] = o[c] + acc * ky[j];
+            }
+        }
+        const long long di = (long long)dy * dst_row_stride + (long long)dx * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (DST_BF16) {
+                const __bf16 hb = (__bf16)o[c];
+                ((unsigned short*)dst)[di + c] = __builtin_bit_cast(unsigned short, hb);
+            } else {
+                ((float*)dst)[di + c] = o[c];
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(long long work, int cap = 4096) {
     long long g = (work + 255) / 256;
     if (g < 1) g = 1;
@@ -340,6 +402,15 @@ extern "C" int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, 
     if (dst_row_stride < (int64_t)Wo * C) return rtn_fail(h, RTN_EINVAL, "resize_cubic: dst_row_stride too small");
     const long long total = (long long)Ho * Wo * C;
     const double inv = 1.0 / scale;
+    if (src_dtype == 2 && C == 3) {
+        dim3 g3(grid_for((long long)Ho * Wo, 16384)), b3(256);
+        if (dst_dtype == RTN_BF16)
+            hipLaunchKernelGGL((resize_cubic_u8c3_kernel<1>), g3, b3, 0, h->stream, (const unsigned char*)src, H, W, inv, dst, Ho, Wo, (long long)dst_row_stride);
+        else
+            hipLaunchKernelGGL((resize_cubic_u8c3_kernel<0>), g3, b3, 0, h->stream, (const unsigned char*)src, H, W, inv, dst, Ho, Wo, (long long)dst_row_stride);
+        RTN_CHECK_LAUNCH(h, "resize_cubic_u8c3_kernel");
+        return RTN_OK;
+    }
     dim3 g(grid_for(total, 8192)), b(256);
 #define RS(S, D) hipLaunchKernelGGL((resize_cubic_kernel<S, D>), g, b, 0, h->stream, src, H, W, C, inv, dst, Ho, Wo, (long long)dst_row_stride)
     if (src_dtype == 2) { if (dst_dtype == RTN_BF16) RS(1, 1); else RS(1, 0); }
@@ -356,7 +427,7 @@ extern "C" int rtn_resize_cubic(rtn_handle_t h, const void* src, int src_dtype, 
 // (sum + 2^14) >> 15.  Integer work from the two products on: bit-exact against oracle/ref_generator.py.
 struct WarpParams {
     double m[6];
-    int H, W, C, interp, border;
+    int H, W, C, interp, border, dword_rows;
     unsigned char cval[4];
 };
 
@@ -377,41 +448,71 @@ __device__ __forceinline__ int border_index(int p, int len, int mode) {
 }
 
 __global__ __launch_bounds__(256) void warp_affine_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, WarpParams p) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.W || y >= p.H) return;
-    const int round_delta = p.interp ? 16 : 512;
-    const int X0 = __double2int_rn((p.m[1] * (double)y + p.m[2]) * 1024.0) + round_delta;
-    const int Y0 = __double2int_rn((p.m[4] * (double)y + p.m[5]) * 1024.0) + round_delta;
-    const int ax = __double2int_rn(p.m[0] * (double)x * 1024.0), bx = __double2int_rn(p.m[3] * (double)x * 1024.0);
-    const int sh = p.interp ? 5 : 10;
-    int X = (X0 + ax) >> sh, Y = (Y0 + bx) >> sh;
-    int sx, sy, fa = 0, fb = 0;
-    if (p.interp) { sx = X >> 5; sy = Y >> 5; fa = X & 31; fb = Y & 31; }
-    else { sx = X; sy = Y; }
-    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
-    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
-    unsigned char* o = dst + ((long long)y * p.W + x) * p.C;
-    if (!p.interp) {
-        const int ix = border_index(sx, p.W, p.border), iy = border_index(sy, p.H, p.border);
-        for (int c = 0; c < p.C; ++c) o[c] = (ix < 0 || iy < 0) ? p.cval[c] : src[((long long)iy * p.W + ix) * p.C + c];
-        return;
+    __shared__ unsigned int tile[4][64];                  // one destination row segment per wave: 64 px * C bytes
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lx, y = blockIdx.y * 4 + ly;
+    const bool live = x < p.W && y < p.H;
+    unsigned char o[4] = {0, 0, 0, 0};
+    if (live) {
+        const int round_delta = p.interp ? 16 : 512;
+        const int X0 = __double2int_rn((p.m[1] * (double)y + p.m[2]) * 1024.0) + round_delta;
+        const int Y0 = __double2int_rn((p.m[4] * (double)y + p.m[5]) * 1024.0) + round_delta;
+        const int ax = __double2int_rn(p.m[0] * (double)x * 1024.0), bx = __double2int_rn(p.m[3] * (double)x * 1024.0);
+        const int sh = p.interp ? 5 : 10;
+        const int X = (X0 + ax) >> sh, Y = (Y0 + bx) >> sh;
+        int sx, sy, fa = 0, fb = 0;
+        if (p.interp) { sx = X >> 5; sy = Y >> 5; fa = X & 31; fb = Y & 31; }
+        else { sx = X; sy = Y; }
+        sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+        sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+        if (!p.interp) {
+            const int ix = border_index(sx, p.W, p.border), iy = border_index(sy, p.H, p.border);
+            for (int c = 0; c < p.C; ++c) o[c] = (ix < 0 || iy < 0) ? p.cval[c] : src[((long long)iy * p.W + ix) * p.C + c];
+        } else if (p.border == 0 && (sx >= p.W || sx + 1 < 0 || sy >= p.H || sy + 1 < 0)) {
+            for (int c = 0; c < p.C; ++c) o[c] = p.cval[c];
+        } else {
+            int w[4] = {32 * (32 - fa) * (32 - fb), 32 * fa * (32 - fb), 32 * (32 - fa) * fb, 32 * fa * fb};
+            if (w[0] > 32767) w[0] = 32767;
+            const long long a0 = ((long long)sy * p.W + sx) * 3, a1 = a0 + (long long)p.W * 3;
+            if (p.C == 3 && sx >= 0 && sx + 1 < p.W && sy >= 0 && sy + 1 < p.H && a1 + 8 <= (long long)p.H * p.W * 3) {
+                // all four taps on the page: each source row's two pixels are 6 contiguous bytes, fetched as one unaligned 8-byte load
+                unsigned long long q0, q1;
+                __builtin_memcpy(&q0, src + a0, 8);
+                __builtin_memcpy(&q1, src + a1, 8);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int v00 = (int)((q0 >> (8 * c)) & 0xff), v01 = (int)((q0 >> (8 * (c + 3))) & 0xff);
+                    const int v10 = (int)((q1 >> (8 * c)) & 0xff), v11 = (int)((q1 >> (8 * (c + 3))) & 0xff);
+                    const int r = (v00 * w[0] + v01 * w[1] + v10 * w[2] + v11 * w[3] + (1 << 14)) >> 15;
+                    o[c] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                }
+            } else {
+                const int x0 = border_index(sx, p.W, p.border), x1 = border_index(sx + 1, p.W, p.border);
+                const int y0 = border_index(sy, p.H, p.border), y1 = border_index(sy + 1, p.H, p.border);
+                for (int c = 0; c < p.C; ++c) {
+                    const int cv = p.cval[c];
+                    const int v00 = (x0 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x0) * p.C + c];
+                    const int v01 = (x1 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x1) * p.C + c];
+                    const int v10 = (x0 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x0) * p.C + c];
+                    const int v11 = (x1 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x1) * p.C + c];
+                    const int r = (v00 * w[0] + v01 * w[1] + v10 * w[2] + v11 * w[3] + (1 << 14)) >> 15;
+                    o[c] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                }
+            }
+        }
     }
-    if (p.border == 0 && (sx >= p.W || sx + 1 < 0 || sy >= p.H || sy + 1 < 0)) {
-        for (int c = 0; c < p.C; ++c) o[c] = p.cval[c];
-        return;
-    }
-    int w[4] = {32 * (32 - fa) * (32 - fb), 32 * fa * (32 - fb), 32 * (32 - fa) * fb, 32 * fa * fb};
-    if (w[0] > 32767) w[0] = 32767;
-    const int x0 = border_index(sx, p.W, p.border), x1 = border_index(sx + 1, p.W, p.border);
-    const int y0 = border_index(sy, p.H, p.border), y1 = border_index(sy + 1, p.H, p.border);
-    for (int c = 0; c < p.C; ++c) {
-        const int cv = p.cval[c];
-        const int v00 = (x0 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x0) * p.C + c];
-        const int v01 = (x1 < 0 || y0 < 0) ? cv : src[((long long)y0 * p.W + x1) * p.C + c];
-        const int v10 = (x0 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x0) * p.C + c];
-        const int v11 = (x1 < 0 || y1 < 0) ? cv : src[((long long)y1 * p.W + x1) * p.C + c];
-        int r = (v00 * w[0] + v01 * w[1] + v10 * w[2] + v11 * w[3] + (1 << 14)) >> 15;
-        o[c] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    // a full 64-pixel segment of a 3-channel page whose rows are dword aligned leaves as 48 coalesced dwords per row
+    const bool packed = p.dword_rows && (int)blockIdx.x * 64 + 64 <= p.W;
+    if (packed) {
+        unsigned char* tb = (unsigned char*)tile[ly];
+        tb[lx * 3 + 0] = o[0];
+        tb[lx * 3 + 1] = o[1];
+        tb[lx * 3 + 2] = o[2];
+        __syncthreads();
+        if (lx < 48 && y < p.H) ((unsigned int*)(dst + ((long long)y * p.W + (long long)blockIdx.x * 64) * 3))[lx] = tile[ly][lx];
+    } else if (live) {
+        unsigned char* d = dst + ((long long)y * p.W + x) * p.C;
+        for (int c = 0; c < p.C; ++c) d[c] = o[c];
     }
 }
 
@@ -429,6 +530,7 @@ extern "C" int rtn_warp_affine_u8(rtn_handle_t h, const uint8_t* src, int H, int
         p.m[i] = inv_map6[i];
     }
     p.H = H; p.W = W; p.C = C; p.interp = interpolation; p.border = border_mode;
+    p.dword_rows = C == 3 && (W * 3) % 4 == 0 && ((uintptr_t)dst & 3) == 0;
     for (int c = 0; c < 4; ++c) p.cval[c] = cval4 ? cval4[c] : 0;
     hipLaunchKernelGGL(warp_affine_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, h->stream, src, dst, p);
     RTN_CHECK_LAUNCH(h, "warp_affine_kernel");
