@@ -15,6 +15,7 @@ L = _pkg._lib
 engine = importlib.import_module(_pkg.__name__ + ".engine")
 weights = importlib.import_module(_pkg.__name__ + ".weights")
 trainer = importlib.import_module(_pkg.__name__ + ".trainer")
+keras_h5 = importlib.import_module(_pkg.__name__ + ".keras_h5")
 
 _handle = None
 

@@ -173,16 +173,24 @@ class Model:
         return root._state
 
     def save_weights(self, path):
-        np.savez(path, **self.get_state())
+        """Keras layer names and layouts either way: '*.h5' / '*.hdf5' -> a Keras save_weights() HDF5 file written by keras_h5.py
+        (RetinaNet.py:70-79,153-163 save .h5), anything else -> .npz."""
+        if str(path).endswith((".h5", ".hdf5")):
+            _rt.keras_h5.save_keras_weights(path, self.get_state())
+        else:
+            np.savez(path, **self.get_state())
 
     save = save_weights
 
     def load_weights(self, path, by_name=True, skip_mismatch=False):
         root = self._root()
-        if str(path).endswith((".h5", ".hdf5")):
-            raise ImportError("Keras HDF5 checkpoints need h5py (not available here); convert to .npz with the reference's layer names")
-        data = np.load(path, allow_pickle=False)
-        for k in data.files:
+        if str(path).endswith((".h5", ".hdf5")):             # RetinaNet.py:320-340 loads training-*.h5 / inferModel.h5
+            data = _rt.keras_h5.load_keras_state(path)
+            names = list(data)
+        else:
+            data = np.load(path, allow_pickle=False)
+            names = data.files
+        for k in names:
             if k in root._state:
                 if root._state[k].shape != data[k].shape:
                     if skip_mismatch:
