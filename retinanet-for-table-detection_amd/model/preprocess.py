@@ -13,11 +13,9 @@ def preprocess_pages(pages, return_binary=False):
     """pages: uint8 (B,H,W,3) BGR or (B,H,W) gray, or one (H,W[,3]) page.  Returns uint8 (B,H,W,3): b=L2, g=L1, r=C distance
     maps of the Gaussian adaptive threshold, saturated to uint8 as cv2.imwrite stores them."""
     a = np.asarray(pages)
-    single = a.ndim == 2 or (a.ndim == 3 and a.shape[-1] == 3 and a.dtype == np.uint8 and False)
-    if a.ndim == 2:
-        a, single = a[None], True
-    elif a.ndim == 3 and a.shape[-1] == 3:
-        a, single = a[None], True
+    single = a.ndim == 2 or (a.ndim == 3 and a.shape[-1] == 3)        # one gray (H,W) or one BGR (H,W,3) page
+    if single:
+        a = a[None]
     ch = 3 if a.ndim == 4 else 1
     if a.dtype != np.uint8:
         raise ValueError("pages must be uint8")

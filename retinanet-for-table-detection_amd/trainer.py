@@ -16,7 +16,6 @@ flags of the dgrad launch or by the small kernels of rtn_backward.hip.  All arit
 provides memory, the stream and (optionally) torch.distributed for the gradient all-reduce.
 """
 import ctypes as C
-import math
 
 import numpy as np
 import os

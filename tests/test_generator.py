@@ -5,7 +5,6 @@ cv2.warpAffine restatement (parity unpinned at bit level: no OpenCV here, no aug
 import importlib
 import os
 import random
-import sys
 import types
 import warnings
 
