@@ -34,7 +34,7 @@ extern "C" {
 
 typedef struct rtn_ctx* rtn_handle_t;
 
-typedef enum { RTN_BF16 = 0, RTN_F32 = 1 } rtn_dtype_t;
+typedef enum { RTN_BF16 = 0, RTN_F32 = 1, RTN_FP8 = 3 /* OCP e4m3fn bytes; rtn_conv2d_fp8_fwd / rtn_quantize_fp8 only */ } rtn_dtype_t;
 
 #define RTN_MAX_GROUPS 5      /* pyramid levels P3..P7 in one grouped launch */
 #define RTN_MAX_GT     64     /* ground-truth boxes per image (anchor targets) */
@@ -147,6 +147,22 @@ typedef struct {
     int32_t step;            /* 1 or the shortcut's stride                             */
 } rtn_conv_src2_t;
 int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2);
+
+/* fp8 (OCP e4m3fn) convolution for BASELINE.json configs[4] ("fp8 MFMA convs", the head towers default_classification_model /
+ * default_regression_model, model/defineModel.py:78-167): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, f32 accumulate.
+ *   d->dtype = RTN_FP8: `in` and `w` are e4m3 bytes, i.e. quantised x * s_x and w * s_w with per-tensor scales the caller chose;
+ *   d: stride-1 'same' KHxKW layer (KW 2..4) over dense NHWC inputs, Crun a multiple of 128, N and out_ld multiples of 8,
+ *      flags = 0 or RTN_CONV_RELU, bias f32 (unscaled) or NULL; grouped levels as for rtn_conv2d_fwd.
+ *   y = acc * acc_scale + bias  (acc_scale = 1 / (s_x * s_w));  ReLU if flagged;
+ *   out_dtype RTN_BF16: out = bf16(y);   RTN_FP8: out = e4m3(clamp(y * out_scale, -448, 448)), round to nearest even.
+ * rtn_quantize_fp8: dst[i] = e4m3(clamp(src[i] * scale, -448, 448)) for a bf16 / f32 tensor of n elements (n % 8 == 0). */
+typedef struct {
+    float acc_scale;
+    float out_scale;
+    int32_t out_dtype;
+} rtn_conv_fp8_t;
+int rtn_conv2d_fp8_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_fp8_t* q);
+int rtn_quantize_fp8(rtn_handle_t h, const void* src, int src_dtype, void* dst, int64_t n, float scale);
 
 /* Data gradient (what TF autodiff emits as Conv2DBackpropInput under fit_generator, RetinaNet.py:280).  The same
  * implicit GEMM run on dY: `in` = dY, `w` = the forward weights re-packed by rtn_pack_dgrad_weights

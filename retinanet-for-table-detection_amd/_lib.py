@@ -15,7 +15,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librtn.so")
 
-RTN_BF16, RTN_F32, RTN_U8 = 0, 1, 2
+RTN_BF16, RTN_F32, RTN_U8, RTN_FP8 = 0, 1, 2, 3
 RTN_MAX_GROUPS, RTN_MAX_GT, RTN_MAX_DET = 5, 64, 300
 
 CONV_RELU, CONV_SIGMOID, CONV_RES_SAME, CONV_RES_UPSAMPLE, CONV_OUT_F32, CONV_RELU_MASK, CONV_MASK_PRE = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
@@ -72,6 +72,10 @@ class AnchorCfg(C.Structure):
     ]
 
 
+class ConvFp8(C.Structure):
+    _fields_ = [("acc_scale", C.c_float), ("out_scale", C.c_float), ("out_dtype", C.c_int32)]
+
+
 # every symbol include/rtn.h declares: (restype, argtypes)
 _P, _I, _I64, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 SIGNATURES = {
@@ -122,6 +126,8 @@ SIGNATURES = {
     "rtn_preprocess_dt3": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _SZ]),
     "rtn_distance_transform3": (_I, [_P, _P, _I, _I, _I, _P, _P, _SZ]),
     "rtn_resize_cubic": (_I, [_P, _P, _I, _I, _I, _I, _D, _P, _I, _I, _I, _I64]),
+    "rtn_conv2d_fp8_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvFp8)]),
+    "rtn_quantize_fp8": (_I, [_P, _P, _I, _P, _I64, _F]),
     "rtn_warp_affine_u8": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
     "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),

@@ -120,12 +120,32 @@ struct KParams {
     // register layout to `scratch`); a second, tiny launch of the same kernel (tail_mode 2) sums the slices in order and runs
     // the epilogue.  tail_mode: 0 off, 1 main launch, 2 finish launch.
     int tail_mode, tail_main, tail_tiles, tail_slices, tail_per;   // tail_per: K steps (v2) / (kh,chunk) groups (v3) per slice
+    // fp8 (OCP e4m3) operands, halo kernel only: y = acc * acc_scale + bias; stored as bf16, or as fp8 of sat(y * out_scale)
+    float acc_scale, out_scale;
+    int out_fp8;
     int korder_chunks, korder_kw;   // 256-row kernel: K-step visiting order (see KOrder in the kernel); {nkt, 1} = in order
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
+}
+
+// fp8 e4m3 x fp8 e4m3, K = 128 per instruction (twice the bf16 rate): a lane supplies 32 bytes of its row per operand.  Which 32 of
+// the row's 128 K positions a lane holds is free as long as A and B agree (the instruction pairs equal (lane group, byte) slots),
+// so the two 16-byte fragments are the ones the bf16 loop reads for ks = 0 and 1.  Block scales are 2^0 (E8M0 127).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_step_fp8(f32x4& acc, const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    const i32x8 A = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8 B = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
 }
 
 template <int ES>
@@ -310,6 +330,35 @@ __device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup&
                 op[j] = __builtin_bit_cast(unsigned short, hb);
             }
         }
+    }
+}
+
+// fp8 layers: bias (+ ReLU) only; the accumulator carries (activation scale x weight scale)^-1, undone by acc_scale.
+__device__ __forceinline__ void epilogue_fp8(const KParams& p, const KGroup& G, const RowRef& r, int n, float (&v)[8], const float (&bv)[8]) {
+    if (!r.valid) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = v[j] * p.acc_scale + bv[j];
+        if (p.flags & RTN_CONV_RELU) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    const long long oidx = (long long)r.b * G.out_img_stride + G.out_off + r.opix * p.out_ld + n;
+    if (p.out_fp8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float q = v[j] * p.out_scale;
+            v[j] = q > 448.f ? 448.f : (q < -448.f ? -448.f : q);
+        }
+        uint2 o;
+        o.x = pack_fp8x4(v[0], v[1], v[2], v[3]);
+        o.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(G.out) + oidx) = o;
+    } else {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(G.out) + oidx) = o;
     }
 }
 
@@ -1038,6 +1087,30 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
         const char* A_ = lds + abuf * A_BYTES + rr * 128;
         const char* B_ = lds + B_BASE + bcur * B_BYTES + b_row_off;
         const unsigned em = emask >> kw;
+        if constexpr (ES == 1) {                      // fp8: the row's two fragment halves feed ONE K = 128 instruction
+            const int rdA0 = (kq ^ swz) << 4, rdA1 = ((4 + kq) ^ swz) << 4;
+            const int rdB0 = (kq ^ (lrow & 7)) << 4, rdB1 = ((4 + kq) ^ (lrow & 7)) << 4;
+            uint4 a0_[MI], a1_[MI];
+#pragma unroll
+            for (int i_ = 0; i_ < MI; ++i_) {
+                a0_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rdA0);
+                a1_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rdA1);
+                if ((em >> (i_ * 4)) & 1u) { a0_[i_] = make_uint4(0u, 0u, 0u, 0u); a1_[i_] = a0_[i_]; }
+            }
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += NJ) {
+                uint4 b0_[NJ], b1_[NJ];
+#pragma unroll
+                for (int j_ = 0; j_ < NJ; ++j_) {
+                    b0_[j_] = *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rdB0);
+                    b1_[j_] = *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rdB1);
+                }
+#pragma unroll
+                for (int i_ = 0; i_ < MI; ++i_)
+#pragma unroll
+                    for (int j_ = 0; j_ < NJ; ++j_) mma_step_fp8(acc[i_][jh + j_], a0_[i_], a1_[i_], b0_[j_], b1_[j_]);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int rdA = ((ks * 4 + kq) ^ swz) << 4;
@@ -1058,6 +1131,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
 #pragma unroll
                     for (int j_ = 0; j_ < NJ; ++j_) mma_step<ES>(acc[i_][jh + j_], a_[i_], b_[j_]);
             }
+        }
         }
         // The B tile of step kt+1 must have landed.  Operations issued after it may stay in flight (vmcnt retires in
         // order): with a 3-stage ring the B tile staged this step, plus a halo (4 pieces) staged this or the previous step.
@@ -1135,7 +1209,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
             const float4 v0 = *reinterpret_cast<const float4*>(sp);
             const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+            if constexpr (ES == 1) epilogue_fp8(p, G, rows[it], n, v, bv);
+            else epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
@@ -1162,10 +1237,18 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr) {
+static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr, const rtn_conv_fp8_t* q8 = nullptr) {
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
-    if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
+    if (d->dtype != RTN_BF16 && d->dtype != RTN_F32 && !(d->dtype == RTN_FP8 && q8)) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
+    if (q8) {
+        if (d->dtype != RTN_FP8) return rtn_fail(h, RTN_EINVAL, "conv fp8: the descriptor's dtype must be RTN_FP8");
+        if (s2) return rtn_fail(h, RTN_EINVAL, "conv fp8: no second source");
+        if (d->flags & ~RTN_CONV_RELU) return rtn_fail(h, RTN_EINVAL, "conv fp8: only bias and ReLU epilogues (flags 0x%x)", d->flags);
+        if (q8->out_dtype != RTN_FP8 && q8->out_dtype != RTN_BF16) return rtn_fail(h, RTN_EINVAL, "conv fp8: output must be fp8 or bf16");
+        if (!(q8->acc_scale > 0.f) || !(q8->out_scale > 0.f)) return rtn_fail(h, RTN_EINVAL, "conv fp8: scales must be positive");
+        if (d->N % 8 || d->out_ld % 8) return rtn_fail(h, RTN_EINVAL, "conv fp8: N and out_ld must be multiples of 8");
+    }
     const int es = rtn_dtype_size(d->dtype);
     const bool out_f32 = (d->dtype == RTN_F32) || (d->flags & RTN_CONV_OUT_F32);
     if (d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS) return rtn_fail(h, RTN_EINVAL, "conv: ngroups %d", d->ngroups);
@@ -1257,6 +1340,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             s.in_img_stride != (long long)s.Hin * s.in_row_stride) halo_ok = false;
     }
     if (s2) impl = 2;                                  // only the 256-row per-tap kernel walks a second source
+    if (q8) {                                          // fp8 exists in the halo kernel only
+        if (!halo_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8: only stride-1 'same' KHxKW (KW 2..4) layers over dense NHWC inputs with whole 128-byte channel chunks");
+        impl = 3;
+        bn2 = d->N > 128 ? 256 : 128;
+    }
     if (impl == 3 && !halo_ok) impl = 2;
     // measured (tools/ab_conv.py, RTN_CONV_HALO=0|1): +3..4 % on the 256-channel 3x3 layers (heads, P3, P4, res4), none or a
     // small loss below that, so the narrower layers stay on the per-tap kernel.  RTN_CONV_HALO=2 forces it wherever it applies.
@@ -1324,11 +1412,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         mtiles += (M + TM - 1) / TM;
     }
     (void)out_f32;
+    if (q8 && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8: output strides and offsets must be multiples of 8 elements");
+    if (q8) { p.acc_scale = q8->acc_scale; p.out_scale = q8->out_scale; p.out_fp8 = q8->out_dtype == RTN_FP8 ? 1 : 0; }
     if ((d->flags & RTN_CONV_RELU_MASK) && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv: RELU_MASK needs N, out_ld, strides multiples of 8");
     int BN = impl >= 2 ? bn2 : (d->N <= 64 ? 64 : 128);
     if (impl >= 2) {
         const int bn_env = rtn_env_int("RTN_CONV_BN2", 0);   // A/B override of the 256-row kernel's tile width
-        if ((bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
+        if (!q8 && (bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
     }
     p.w = (const char*)d->w;
     p.bias = d->bias;
@@ -1382,7 +1472,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     dim3 gdim((unsigned)grid);
     // ---- tail split (see KParams): the grid is a few tiles over a whole number of rounds of the resident slots
     int tail_tiles = 0;
-    if (impl >= 2 && d->ngroups == 1 && !s2 && rtn_env_int("RTN_CONV_TAIL", 1) != 0) {
+    if (impl >= 2 && d->ngroups == 1 && !s2 && !q8 && rtn_env_int("RTN_CONV_TAIL", 1) != 0) {
         long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * (BN == 64 ? 2 : 1);
         { const int sl_env = rtn_env_int("RTN_CONV_TAIL_SLOTS", 0); if (sl_env > 0) slots = sl_env; }   // tests: pretend a small chip
         const long long rest = grid % slots;
@@ -1439,7 +1529,8 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         }                                                                                                \
         hipLaunchKernelGGL((conv_igemm3_kernel<E, B>), gdim, bdim, ldsb, h->stream, p);                  \
     } while (0)
-        if (es == 2) { if (BN == 64) RTN_L3(2, 64); else if (BN == 128) RTN_L3(2, 128); else RTN_L3(2, 256); }
+        if (es == 1) { if (BN == 128) RTN_L3(1, 128); else RTN_L3(1, 256); }
+        else if (es == 2) { if (BN == 64) RTN_L3(2, 64); else if (BN == 128) RTN_L3(2, 128); else RTN_L3(2, 256); }
         else         { if (BN == 64) RTN_L3(4, 64); else if (BN == 128) RTN_L3(4, 128); else RTN_L3(4, 256); }
 #undef RTN_L3
     } else if (impl == 2) {
@@ -1551,6 +1642,12 @@ extern "C" int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, co
     if (!h) return RTN_EINVAL;
     if (!s2) return rtn_fail(h, RTN_EINVAL, "conv dual: null second source");
     return conv_launch(h, d, s2);
+}
+
+extern "C" int rtn_conv2d_fp8_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_fp8_t* q) {
+    if (!h) return RTN_EINVAL;
+    if (!q) return rtn_fail(h, RTN_EINVAL, "conv fp8: null scale block");
+    return conv_launch(h, d, nullptr, q);
 }
 
 extern "C" int rtn_conv2d_dgrad(rtn_handle_t h, const rtn_conv_desc_t* d) {

@@ -233,6 +233,52 @@ extern "C" int rtn_relu(rtn_handle_t h, const void* in, void* out, int dtype, in
 }
 
 namespace {
+// activations entering an fp8 layer: e4m3(clamp(x * scale, +-448)), 8 elements per thread (16 B of bf16 / 32 B of f32 in, 8 B out)
+template <int ES>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const void* __restrict__ src, uint2* __restrict__ dst, long long nvec, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        if (ES == 2) {
+            const uint4 q = reinterpret_cast<const uint4*>(src)[i];
+            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] = __uint_as_float(w4[j] << 16);
+                v[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
+            }
+        } else {
+            const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q = v[j] * scale;
+            v[j] = q > 448.f ? 448.f : (q < -448.f ? -448.f : q);
+        }
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+        dst[i] = make_uint2(lo, hi);
+    }
+}
+}  // namespace
+
+extern "C" int rtn_quantize_fp8(rtn_handle_t h, const void* src, int src_dtype, void* dst, int64_t n, float scale) {
+    if (!h) return RTN_EINVAL;
+    if (!src || !dst || n < 1 || !(scale > 0.f)) return rtn_fail(h, RTN_EINVAL, "quantize_fp8: bad argument");
+    if (src_dtype != RTN_BF16 && src_dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "quantize_fp8: source must be bf16 or f32");
+    if (n % 8 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return rtn_fail(h, RTN_EINVAL, "quantize_fp8: n must be a multiple of 8, src 16-byte and dst 8-byte aligned");
+    const long long nvec = n / 8;
+    dim3 g(grid_for(nvec)), b(256);
+    if (src_dtype == RTN_BF16) hipLaunchKernelGGL((quantize_fp8_kernel<2>), g, b, 0, h->stream, src, (uint2*)dst, nvec, scale);
+    else                       hipLaunchKernelGGL((quantize_fp8_kernel<4>), g, b, 0, h->stream, src, (uint2*)dst, nvec, scale);
+    RTN_CHECK_LAUNCH(h, "quantize_fp8_kernel");
+    return RTN_OK;
+}
+
+namespace {
 // UpsampleLike (model/layers.py:89-98): legacy TF nearest, src = min(floor(dst * in/out), in-1), ratio in float32
 __global__ __launch_bounds__(256) void upsample_nearest_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Hs, int Ws,
                                                                int Hd, int Wd, int cv, float rh, float rw) {

@@ -63,7 +63,7 @@ inline float* rtn_splitk_scratch(rtn_ctx* h) {
                             hipGetErrorString(e_));                                        \
     } while (0)
 
-static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : 2; }
+static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }
 
 // bf16 helpers on raw bits (device + host)
 __host__ __device__ static inline float rtn_bf16_to_f32(unsigned short b) {

@@ -1,0 +1,160 @@
+"""GPU: the fp8 (OCP e4m3fn) halo convolution rtn_conv2d_fp8_fwd and rtn_quantize_fp8 (BASELINE.json configs[4], "fp8 MFMA convs").
+
+Reference: the SAME e4m3 bytes (quantised by torch's float8_e4m3fn cast, round to nearest even) multiplied in float64 by a torch
+convolution.  Products of two e4m3 values are exact in f32 and the kernel accumulates in f32, so only the summation order differs:
+the bf16 output is held to 1e-2 relative (one bf16 rounding), the fp8 output to "the same e4m3 code except where the value sits
+on a rounding boundary": at most 1 code apart - or, for values near zero where codes are dense, within 1e-4 of the output scale in
+absolute terms (the f8f6f4 MFMA's accumulation noise floor measures 3e-5 of the output scale: tools/fp8_diag.py) - and different
+from the reference code on fewer than 1 % of the elements (measured 0.04 %).  Tolerance of an fp8 NETWORK against the float64
+oracle is a separate statement (tests below, engine level)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+
+
+def to_f8(x, scale):
+    return torch.clamp(x * scale, -448.0, 448.0).to(F8)
+
+
+def code_distance(a_u8, b_u8):
+    """Distance in e4m3 codes between two byte tensors (sign-magnitude -> monotone integer)."""
+    def mono(u):
+        u = u.to(torch.int32)
+        mag = u & 0x7f
+        return torch.where((u & 0x80) != 0, -mag, mag)
+    return (mono(a_u8) - mono(b_u8)).abs()
+
+
+def test_quantize_fp8_matches_torch_cast(pkg, handle):
+    g = torch.Generator().manual_seed(0)
+    for dt, code in ((torch.bfloat16, 0), (torch.float32, 1)):
+        x = (torch.randn(4096 * 8, generator=g) * 3).to(dt).cuda()
+        x[:8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 500.0, -500.0, 17.0, 0.0302734375], dtype=dt)
+        for scale in (1.0, 37.5, 0.013):
+            out = torch.empty(x.numel(), dtype=torch.uint8, device="cuda")
+            handle.check(pkg.lib.rtn_quantize_fp8(handle.raw, x.data_ptr(), code, out.data_ptr(), x.numel(), scale))
+            torch.cuda.synchronize()
+            want = to_f8(x.float() * 1.0, scale).view(torch.uint8)
+            # the device multiplies in f32 exactly like the reference; -0.0 keeps its sign bit in both
+            assert torch.equal(out, want), int((out != want).sum())
+    assert pkg.lib.rtn_quantize_fp8(handle.raw, x.data_ptr(), 1, out.data_ptr(), 12, 1.0) == -1
+
+
+def run_fp8(pkg, handle, levels, cin, cout, k, relu, out_fp8, B=2, seed=0):
+    L = pkg._lib
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(k, k, cin, cout, generator=g) / math.sqrt(k * k * cin)
+    bias = torch.randn(cout, generator=g)
+    sw = 448.0 / float(w.abs().max())
+    wq = to_f8(w, sw)
+    rows = -(-cout // 128) * 128
+    wk = torch.zeros(rows, k * k * cin, dtype=torch.uint8)
+    wk[:cout] = wq.view(torch.uint8).permute(3, 0, 1, 2).reshape(cout, -1)
+    wk = wk.cuda()
+    bk = torch.zeros(rows)
+    bk[:cout] = bias
+    bk = bk.cuda()
+    xs = [torch.randn(B, H, W, cin, generator=g) * 2 for H, W in levels]
+    sx = 448.0 / max(float(x.abs().max()) for x in xs)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, L.RTN_FP8
+    d.w, d.bias, d.w_rows, d.N, d.KH, d.KW = wk.data_ptr(), bk.data_ptr(), rows, cout, k, k
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = (k - 1) // 2
+    d.out_ld = cout
+    d.flags = L.CONV_RELU if relu else 0
+    keep, outs, wants = [], [], []
+    so = 1.0
+    ys = []
+    for x in xs:
+        xq = to_f8(x, sx)
+        y = F.conv2d(xq.double().permute(0, 3, 1, 2), wq.double().permute(3, 2, 0, 1), None, padding=(k - 1) // 2)
+        y = y.permute(0, 2, 3, 1) / (sx * sw) + bias.double()
+        if relu:
+            y = y.clamp_min(0)
+        ys.append(y)
+        keep.append(xq.view(torch.uint8).cuda().contiguous())
+    if out_fp8:
+        so = 448.0 / max(float(y.abs().max()) for y in ys) * 0.9
+    for gi, ((H, W), xq_dev, y) in enumerate(zip(levels, keep[:len(levels)], ys)):
+        grp = d.g[gi]
+        grp.in_, grp.in_elems = xq_dev.data_ptr(), xq_dev.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        o = torch.full((B, H, W, cout), 7, dtype=torch.uint8 if out_fp8 else torch.bfloat16, device="cuda")
+        grp.out, grp.out_elems, grp.out_img_stride = o.data_ptr(), o.numel(), H * W * cout
+        outs.append(o)
+        wants.append(y)
+    qd = L.ConvFp8(acc_scale=1.0 / (sx * sw), out_scale=so, out_dtype=L.RTN_FP8 if out_fp8 else L.RTN_BF16)
+    handle.check(pkg.lib.rtn_conv2d_fp8_fwd(handle.raw, C.byref(d), C.byref(qd)))
+    torch.cuda.synchronize()
+    return outs, wants, so
+
+
+@pytest.mark.parametrize("levels,cin,cout,k,relu", [
+    ([(19, 23)], 256, 256, 3, True),
+    ([(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)], 256, 256, 3, True),      # the five pyramid levels of a tower layer, grouped
+    ([(17, 31)], 128, 128, 3, False),
+    ([(9, 300)], 256, 192, 3, True),                                           # N not a multiple of the tile width
+    ([(30, 33)], 512, 256, 3, False),
+])
+def test_fp8_conv_bf16_output(pkg, handle, levels, cin, cout, k, relu):
+    outs, wants, _ = run_fp8(pkg, handle, levels, cin, cout, k, relu, out_fp8=False)
+    for o, w in zip(outs, wants):
+        got = o.double().cpu()
+        scale = float(w.abs().max())
+        assert torch.isfinite(got).all()
+        assert float((got - w).abs().max()) <= 1e-2 * scale, float((got - w).abs().max()) / scale
+
+
+@pytest.mark.parametrize("levels,cin,cout,relu", [
+    ([(19, 23)], 256, 256, True),
+    ([(25, 42), (13, 21), (7, 11)], 256, 256, True),
+    ([(21, 18)], 256, 256, False),
+])
+def test_fp8_conv_fp8_output(pkg, handle, levels, cin, cout, relu):
+    outs, wants, so = run_fp8(pkg, handle, levels, cin, cout, 3, relu, out_fp8=True, seed=3)
+    for o, w in zip(outs, wants):
+        want = to_f8(w.float(), so)
+        got = o.cpu()
+        dist = code_distance(got, want.view(torch.uint8))
+        absdiff = (got.view(F8).float() - want.float()).abs()
+        ok = (dist <= 1) | (absdiff <= 1e-4 * 448.0)
+        assert bool(ok.all()), (int(dist.max()), float(absdiff[~ok].max()))
+        assert float((dist > 0).float().mean()) < 0.01, float((dist > 0).float().mean())
+
+
+def test_fp8_conv_rejects_what_it_does_not_implement(pkg, handle):
+    L = pkg._lib
+    x = torch.zeros(1, 8, 8, 256, dtype=torch.uint8, device="cuda")
+    w = torch.zeros(256, 9 * 256, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(1, 8, 8, 256, dtype=torch.bfloat16, device="cuda")
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, 1, L.RTN_FP8
+    d.w, d.w_rows, d.N, d.KH, d.KW, d.Crun, d.pix_stride, d.sy, d.sx, d.pad_t, d.pad_l, d.out_ld = w.data_ptr(), 256, 256, 3, 3, 256, 256, 1, 1, 1, 1, 256
+    g = d.g[0]
+    g.in_, g.in_elems, g.in_img_stride, g.in_row_stride, g.Hin, g.Win, g.Hout, g.Wout = x.data_ptr(), x.numel(), 8 * 8 * 256, 8 * 256, 8, 8, 8, 8
+    g.out, g.out_elems, g.out_img_stride = o.data_ptr(), o.numel(), 8 * 8 * 256
+    q = L.ConvFp8(acc_scale=1.0, out_scale=1.0, out_dtype=L.RTN_BF16)
+    f = pkg.lib.rtn_conv2d_fp8_fwd
+    assert f(handle.raw, C.byref(d), C.byref(q)) == 0
+    assert pkg.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -1                 # fp8 descriptors only through the fp8 entry
+    d.flags = L.CONV_SIGMOID
+    assert f(handle.raw, C.byref(d), C.byref(q)) == -1
+    d.flags = 0
+    d.sy = d.sx = 2
+    assert f(handle.raw, C.byref(d), C.byref(q)) == -1 and b"fp8" in pkg.lib.rtn_last_error(handle.raw)
+    d.sy = d.sx = 1
+    q.acc_scale = 0.0
+    assert f(handle.raw, C.byref(d), C.byref(q)) == -1
+    q.acc_scale, q.out_dtype = 1.0, L.RTN_F32
+    assert f(handle.raw, C.byref(d), C.byref(q)) == -1
+    torch.cuda.synchronize()
