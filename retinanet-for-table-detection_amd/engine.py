@@ -89,6 +89,8 @@ class Engine:
         self.weights_version = 0
         self._dual, self._dual_version = {}, -1
         self._side = None
+        self.fp8_scales = None         # set by calibrate_fp8(): the head towers then run in fp8 (inference, bf16 engine)
+        self._w8, self._w8_version = {}, -1
 
     # ------------------------------------------------------------------ weights
     def load_state(self, state):
@@ -141,6 +143,76 @@ class Engine:
                 torch.add(bc, b1, out=bd)
             self._dual_version = self.weights_version
         return self._dual
+
+    # ------------------------------------------------------------------ fp8 head towers (BASELINE.json configs[4])
+    TOWERS = ("pyramid_regression", "pyramid_classification")
+
+    def _fp8_on(self):
+        return self.fp8_scales is not None and self.dtype == "bf16" and not self.training
+
+    def _fp8_weights(self):
+        """e4m3 copies of the eight tower layers' filters, one scale per tensor (448 / max |w|); rebuilt when the weights change."""
+        if self._w8_version != self.weights_version:
+            for prefix in self.TOWERS:
+                for i in range(4):
+                    name = "%s_%d" % (prefix, i)
+                    wk = self.w[name][0].float()
+                    sw = 448.0 / max(float(wk.abs().max()), 1e-30)
+                    wq = torch.clamp(wk * sw, -448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+                    if name in self._w8 and self._w8[name][0].shape == wq.shape:
+                        self._w8[name][0].copy_(wq)                    # descriptors of existing plans keep pointing at it
+                        self._w8[name] = (self._w8[name][0], sw)
+                    else:
+                        self._w8[name] = (wq, sw)
+            self._w8_version = self.weights_version
+        return self._w8
+
+    def calibrate_fp8(self, images, margin=1.25):
+        """Switch the two head towers (4 x [3x3 conv 256 + ReLU] each, model/defineModel.py:78-167 - 38 % of the network's FLOPs
+        at 1024x1024 with ResNet-101) to fp8 e4m3: activations get ONE static scale per tensor, 448 / (margin x max |x|) over the
+        five pyramid levels of a bf16 forward pass of `images`; weights one scale per layer.  The towers' first input is the
+        quantised pyramid, their last layer writes bf16 for the (bf16) output convs.  calibrate_fp8(None) switches back."""
+        self.fp8_scales = None
+        self.plans = {}
+        if images is None:
+            return None
+        if self.dtype != "bf16":
+            raise ValueError("fp8 towers extend the bf16 engine")
+        B, H, W, _ = images.shape
+        self.forward(images)
+        torch.cuda.synchronize(self.device)
+        plan = self._plan(B, H, W)
+
+        def scale_of(tensors):
+            amax = max(float(t.float().abs().max()) for t in tensors)
+            return 448.0 / (margin * max(amax, 1e-20))
+
+        scales = {"in": scale_of(plan["pyr"])}
+        for prefix, acts in plan["tower_acts"].items():
+            for i, levels in enumerate(acts):
+                scales[(prefix, i)] = scale_of(levels)
+        self.fp8_scales = scales
+        self.plans = {}
+        return scales
+
+    def _conv8(self, name, groups, B, s_in, s_out, out_fp8):
+        """One fp8 tower layer (rtn_conv2d_fp8_fwd): bias + ReLU, fp8 or bf16 output."""
+        wq, sw = self._fp8_weights()[name]
+        _, bk, kh, kw, cin, cout = self.w[name]
+        d = L.ConvDesc()
+        for i, g in enumerate(groups):
+            d.g[i] = g
+        d.ngroups, d.batch, d.dtype = len(groups), B, L.RTN_FP8
+        d.w, d.bias = wq.data_ptr(), bk.data_ptr()
+        d.w_rows, d.N, d.KH, d.KW = wq.shape[0], cout, kh, kw
+        d.Crun = d.pix_stride = cin
+        d.sy = d.sx = 1
+        d.pad_t, d.pad_l = (kh - 1) // 2, (kw - 1) // 2
+        d.out_ld, d.flags = cout, L.CONV_RELU
+        q = L.ConvFp8(acc_scale=1.0 / (s_in * sw), out_scale=s_out, out_dtype=L.RTN_FP8 if out_fp8 else L.RTN_BF16)
+        meta = {"name": name, "xs": [g._x for g in groups], "ys": [g._out for g in groups], "res": [None] * len(groups),
+                "kh": kh, "kw": kw, "cin": cin, "cout": cout, "B": B, "fp8": True, "s_in": s_in, "sw": sw}
+        return ("conv8", d, name, meta, q)
 
     # ------------------------------------------------------------------ descriptors
     def _group(self, x, out, Hout, Wout, res=None, out_off=0, out_img_stride=None, res_hw=None):
@@ -203,7 +275,8 @@ class Engine:
 
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W):
-        key = (B, H, W)
+        fp8_on = self._fp8_on()
+        key = (B, H, W, fp8_on)
         if key in self.plans:
             return self.plans[key]
         if self.state is None:
@@ -317,15 +390,28 @@ class Engine:
         classification = buf(B, N, self.K, dtype=torch.float32)
         # ---- heads: every layer is ONE grouped launch over the five levels (weights shared, :217)
         tower_ranges = []
+        tower_acts = {}
+        if fp8_on:                                       # the pyramid, quantised once for both towers
+            pyr8 = [buf(B, *hw(p), 256, dtype=torch.uint8) for p in pyr]
+            for p, p8 in zip(pyr, pyr8):
+                ops.append(("quant", p, p8, self.fp8_scales["in"]))
         for prefix, out_t, per_anchor, last_flags in (("pyramid_regression", regression, 4, L.CONV_OUT_F32),
                                                       ("pyramid_classification", classification, self.K,
                                                        L.CONV_OUT_F32 | L.CONV_SIGMOID)):
             tower_start = len(ops)
-            cur = pyr
+            cur = pyr8 if fp8_on else pyr
+            tower_acts[prefix] = []
             for i in range(4):
-                nxt = [buf(B, *hw(p), 256) for p in pyr]
-                groups = [self._group(ci, ni, *hw(ci)) for ci, ni in zip(cur, nxt)]
-                ops.append(self._conv("%s_%d" % (prefix, i), groups, B, pad=(1, 1), flags=L.CONV_RELU))
+                if fp8_on:
+                    nxt = [buf(B, *hw(p), 256, dtype=torch.uint8 if i < 3 else tdt) for p in pyr]
+                    groups = [self._group(ci, ni, *hw(ci)) for ci, ni in zip(cur, nxt)]
+                    s_in = self.fp8_scales["in"] if i == 0 else self.fp8_scales[(prefix, i - 1)]
+                    ops.append(self._conv8("%s_%d" % (prefix, i), groups, B, s_in, self.fp8_scales[(prefix, i)], out_fp8=i < 3))
+                else:
+                    nxt = [buf(B, *hw(p), 256) for p in pyr]
+                    groups = [self._group(ci, ni, *hw(ci)) for ci, ni in zip(cur, nxt)]
+                    ops.append(self._conv("%s_%d" % (prefix, i), groups, B, pad=(1, 1), flags=L.CONV_RELU))
+                tower_acts[prefix].append(nxt)
                 cur = nxt
             groups = [self._group(ci, out_t, *hw(ci), out_off=cfg.anchor_off[l] * per_anchor, out_img_stride=N * per_anchor)
                       for l, ci in enumerate(cur)]
@@ -347,7 +433,7 @@ class Engine:
                     v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
                 v = [op for op in v if op is not None]
                 variants[(fs, fd)] = (v, self._schedule(v))
-        plan = {"ops": ops, "towers": tower_ranges, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -361,10 +447,12 @@ class Engine:
     def _op_io(op):
         """(tensors read, tensors written) of a plan op, as data pointers."""
         kind = op[0]
-        if kind == "conv":
+        if kind in ("conv", "conv8"):
             m = op[3]
             reads = [t.data_ptr() for t in m["xs"]] + [t.data_ptr() for t in m["res"] if t is not None]
             return reads, [t.data_ptr() for t in m["ys"]]
+        if kind == "quant":
+            return [op[1].data_ptr()], [op[2].data_ptr()]
         if kind == "pack":
             return [], [op[1].data_ptr()]
         if kind == "stem":
@@ -385,7 +473,7 @@ class Engine:
         run on side lanes so that their launch latency and partly filled last rounds of workgroups overlap other work."""
         if op[0] == "relu":
             return 1                                              # between P6 and P7
-        if op[0] != "conv":
+        if op[0] not in ("conv", "conv8"):
             return 0
         name = op[2]
         if name.endswith("_branch1") or name in ("P6", "P7"):
@@ -443,6 +531,8 @@ class Engine:
             raise ValueError("unsupported image dtype %s" % images.dtype)
         images = images.contiguous()
         B, H, W, _ = images.shape
+        if self._fp8_on() and self._w8_version != self.weights_version:
+            self.plans = {k: v for k, v in self.plans.items() if not k[3]}      # new filters: new weight scales in the fp8 ops
         plan = self._plan(B, H, W)
         self._bind_stream()
         fused = self._fused()
@@ -499,6 +589,10 @@ class Engine:
             h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
         elif kind == "dual":
             h.check(lib.rtn_conv1x1_dual_fwd(h.raw, C.byref(op[1]), C.byref(op[3])))
+        elif kind == "conv8":
+            h.check(lib.rtn_conv2d_fp8_fwd(h.raw, C.byref(op[1]), C.byref(op[4])))
+        elif kind == "quant":
+            h.check(lib.rtn_quantize_fp8(h.raw, op[1].data_ptr(), self.rdt, op[2].data_ptr(), op[1].numel(), op[3]))
         elif kind == "stem":
             Bn, Hn, Wn = op[2]
             h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
