@@ -173,7 +173,7 @@ class Engine:
         five pyramid levels of a bf16 forward pass of `images`; weights one scale per layer.  The towers' first input is the
         quantised pyramid, their last layer writes bf16 for the (bf16) output convs.  calibrate_fp8(None) switches back."""
         self.fp8_scales = None
-        self.plans = {}
+        self.plans = {k: v for k, v in self.plans.items() if not k[3]}     # bf16 plans (and a trainer's view of them) stay valid
         if images is None:
             return None
         if self.dtype != "bf16":
@@ -192,7 +192,6 @@ class Engine:
             for i, levels in enumerate(acts):
                 scales[(prefix, i)] = scale_of(levels)
         self.fp8_scales = scales
-        self.plans = {}
         return scales
 
     def _conv8(self, name, groups, B, s_in, s_out, out_fp8):
