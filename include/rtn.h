@@ -162,6 +162,11 @@ typedef struct {
     int32_t out_dtype;
 } rtn_conv_fp8_t;
 int rtn_conv2d_fp8_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_fp8_t* q);
+/* A bf16 layer of rtn_conv2d_fwd (any kernel generation, residual / ReLU epilogues included; not OUT_F32 / SIGMOID) whose
+ * output tensor is written as e4m3(clamp(y * out_scale, -448, 448)) instead of bf16: the producer of an fp8 layer's input
+ * (keras_resnet's branch2a in front of the 3x3 branch2b), so that no separate quantise pass touches the tensor.
+ * `out`, out_elems, out_img_stride, out_off, out_ld count e4m3 bytes. */
+int rtn_conv2d_fwd_fp8out(rtn_handle_t h, const rtn_conv_desc_t* d, float out_scale);
 int rtn_quantize_fp8(rtn_handle_t h, const void* src, int src_dtype, void* dst, int64_t n, float scale);
 
 /* Data gradient (what TF autodiff emits as Conv2DBackpropInput under fit_generator, RetinaNet.py:280).  The same

@@ -128,6 +128,7 @@ SIGNATURES = {
     "rtn_resize_cubic": (_I, [_P, _P, _I, _I, _I, _I, _D, _P, _I, _I, _I, _I64]),
     "rtn_conv2d_fp8_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvFp8)]),
     "rtn_quantize_fp8": (_I, [_P, _P, _I, _P, _I64, _F]),
+    "rtn_conv2d_fwd_fp8out": (_I, [_P, C.POINTER(ConvDesc), _F]),
     "rtn_warp_affine_u8": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, _P]),
     "rtn_retina_loss_fwd": (_I, [_P, _I64, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _SZ]),
     "rtn_retina_loss_workspace_bytes": (_SZ, [_I64]),

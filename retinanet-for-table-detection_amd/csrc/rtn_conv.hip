@@ -306,6 +306,20 @@ __device__ __forceinline__ void epilogue_finish8(const KParams& p, const KGroup&
         for (int j = 0; j < 8; ++j) v[j] = 1.0f / (1.0f + expf(-v[j]));
     }
     const long long oidx = (long long)r.b * G.out_img_stride + G.out_off + r.opix * p.out_ld + n;
+    if constexpr (ES == 2) {
+        if (p.out_fp8) {                               // bf16 layer feeding an fp8 layer: e4m3(clamp(y * out_scale)), vec_ok guaranteed
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float q = v[j] * p.out_scale;
+                v[j] = q > 448.f ? 448.f : (q < -448.f ? -448.f : q);
+            }
+            uint2 o;
+            o.x = pack_fp8x4(v[0], v[1], v[2], v[3]);
+            o.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(G.out) + oidx) = o;
+            return;
+        }
+    }
     const bool out_f32 = (ES == 4) || (flags & RTN_CONV_OUT_F32);
     if (out_f32) {
         float* op = reinterpret_cast<float*>(G.out) + oidx;
@@ -1237,7 +1251,8 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr, const rtn_conv_fp8_t* q8 = nullptr) {
+static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr, const rtn_conv_fp8_t* q8 = nullptr,
+                       float out8_scale = 0.f) {
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32 && !(d->dtype == RTN_FP8 && q8)) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
@@ -1412,6 +1427,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         mtiles += (M + TM - 1) / TM;
     }
     (void)out_f32;
+    if (out8_scale != 0.f) {                           // bf16 layer with e4m3 output
+        if (d->dtype != RTN_BF16 || (d->flags & (RTN_CONV_OUT_F32 | RTN_CONV_SIGMOID)) || !(out8_scale > 0.f))
+            return rtn_fail(h, RTN_EINVAL, "conv fp8-out: a bf16 layer without OUT_F32 / SIGMOID and a positive scale are required");
+        if (!vec_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8-out: N, out_ld, output strides and offsets must be multiples of 8");
+        p.out_fp8 = 1;
+        p.out_scale = out8_scale;
+    }
     if (q8 && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8: output strides and offsets must be multiples of 8 elements");
     if (q8) { p.acc_scale = q8->acc_scale; p.out_scale = q8->out_scale; p.out_fp8 = q8->out_dtype == RTN_FP8 ? 1 : 0; }
     if ((d->flags & RTN_CONV_RELU_MASK) && !vec_ok) return rtn_fail(h, RTN_EINVAL, "conv: RELU_MASK needs N, out_ld, strides multiples of 8");
@@ -1642,6 +1664,12 @@ extern "C" int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, co
     if (!h) return RTN_EINVAL;
     if (!s2) return rtn_fail(h, RTN_EINVAL, "conv dual: null second source");
     return conv_launch(h, d, s2);
+}
+
+extern "C" int rtn_conv2d_fwd_fp8out(rtn_handle_t h, const rtn_conv_desc_t* d, float out_scale) {
+    if (!h) return RTN_EINVAL;
+    if (!(out_scale > 0.f)) return rtn_fail(h, RTN_EINVAL, "conv fp8-out: scale must be positive");
+    return conv_launch(h, d, nullptr, nullptr, out_scale);
 }
 
 extern "C" int rtn_conv2d_fp8_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_fp8_t* q) {

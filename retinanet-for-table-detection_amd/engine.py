@@ -91,6 +91,7 @@ class Engine:
         self._side = None
         self.fp8_scales = None         # set by calibrate_fp8(): the head towers then run in fp8 (inference, bf16 engine)
         self._w8, self._w8_version = {}, -1
+        self.fp8_backbone = False      # calibrate_fp8(..., backbone=True): the 3x3 branch2b layers with >= 128 channels too
 
     # ------------------------------------------------------------------ weights
     def load_state(self, state):
@@ -150,29 +151,39 @@ class Engine:
     def _fp8_on(self):
         return self.fp8_scales is not None and self.dtype == "bf16" and not self.training
 
+    def _fp8_layers(self):
+        names = ["%s_%d" % (prefix, i) for prefix in self.TOWERS for i in range(4)]
+        if self.fp8_backbone:
+            for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
+                if 64 * 2 ** stage >= 128:                    # the halo kernel needs whole 128-byte channel chunks
+                    names += ["res%d%s_branch2b" % (stage + 2, Wt.block_name(self.backbone, stage, b)) for b in range(nblocks)]
+            names.append("P3")
+        return names
+
     def _fp8_weights(self):
-        """e4m3 copies of the eight tower layers' filters, one scale per tensor (448 / max |w|); rebuilt when the weights change."""
-        if self._w8_version != self.weights_version:
-            for prefix in self.TOWERS:
-                for i in range(4):
-                    name = "%s_%d" % (prefix, i)
-                    wk = self.w[name][0].float()
-                    sw = 448.0 / max(float(wk.abs().max()), 1e-30)
-                    wq = torch.clamp(wk * sw, -448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
-                    if name in self._w8 and self._w8[name][0].shape == wq.shape:
-                        self._w8[name][0].copy_(wq)                    # descriptors of existing plans keep pointing at it
-                        self._w8[name] = (self._w8[name][0], sw)
-                    else:
-                        self._w8[name] = (wq, sw)
+        """e4m3 copies of the fp8 layers' (BN-folded) filters, one scale per tensor (448 / max |w|); rebuilt when the weights change."""
+        if self._w8_version != self.weights_version or any(n not in self._w8 for n in self._fp8_layers()):
+            for name in self._fp8_layers():
+                wk = self.w[name][0].float()
+                sw = 448.0 / max(float(wk.abs().max()), 1e-30)
+                wq = torch.clamp(wk * sw, -448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+                if name in self._w8 and self._w8[name][0].shape == wq.shape:
+                    self._w8[name][0].copy_(wq)                        # descriptors of existing plans keep pointing at it
+                    self._w8[name] = (self._w8[name][0], sw)
+                else:
+                    self._w8[name] = (wq, sw)
             self._w8_version = self.weights_version
         return self._w8
 
-    def calibrate_fp8(self, images, margin=1.25):
+    def calibrate_fp8(self, images, margin=1.25, backbone=False):
         """Switch the two head towers (4 x [3x3 conv 256 + ReLU] each, model/defineModel.py:78-167 - 38 % of the network's FLOPs
         at 1024x1024 with ResNet-101) to fp8 e4m3: activations get ONE static scale per tensor, 448 / (margin x max |x|) over the
         five pyramid levels of a bf16 forward pass of `images`; weights one scale per layer.  The towers' first input is the
-        quantised pyramid, their last layer writes bf16 for the (bf16) output convs.  calibrate_fp8(None) switches back."""
+        quantised pyramid, their last layer writes bf16 for the (bf16) output convs.  backbone=True also runs every 3x3 branch2b
+        layer with >= 128 channels in fp8: its producer branch2a writes e4m3 straight from its epilogue (rtn_conv2d_fwd_fp8out),
+        branch2b writes bf16 for the 1x1 branch2c.  calibrate_fp8(None) switches back."""
         self.fp8_scales = None
+        self.fp8_backbone = bool(backbone) and images is not None
         self.plans = {k: v for k, v in self.plans.items() if not k[3]}     # bf16 plans (and a trainer's view of them) stay valid
         if images is None:
             return None
@@ -191,11 +202,14 @@ class Engine:
         for prefix, acts in plan["tower_acts"].items():
             for i, levels in enumerate(acts):
                 scales[(prefix, i)] = scale_of(levels)
+        if self.fp8_backbone:
+            for name, a in plan["a_acts"].items():
+                scales[("a", name)] = scale_of([a])
         self.fp8_scales = scales
         return scales
 
-    def _conv8(self, name, groups, B, s_in, s_out, out_fp8):
-        """One fp8 tower layer (rtn_conv2d_fp8_fwd): bias + ReLU, fp8 or bf16 output."""
+    def _conv8(self, name, groups, B, s_in, s_out, out_fp8, relu=True):
+        """One fp8 layer (rtn_conv2d_fp8_fwd): bias (+ ReLU), fp8 or bf16 output."""
         wq, sw = self._fp8_weights()[name]
         _, bk, kh, kw, cin, cout = self.w[name]
         d = L.ConvDesc()
@@ -207,7 +221,7 @@ class Engine:
         d.Crun = d.pix_stride = cin
         d.sy = d.sx = 1
         d.pad_t, d.pad_l = (kh - 1) // 2, (kw - 1) // 2
-        d.out_ld, d.flags = cout, L.CONV_RELU
+        d.out_ld, d.flags = cout, (L.CONV_RELU if relu else 0)
         q = L.ConvFp8(acc_scale=1.0 / (s_in * sw), out_scale=s_out, out_dtype=L.RTN_FP8 if out_fp8 else L.RTN_BF16)
         meta = {"name": name, "xs": [g._x for g in groups], "ys": [g._out for g in groups], "res": [None] * len(groups),
                 "kh": kh, "kw": kw, "cin": cin, "cout": cout, "B": B, "fp8": True, "s_in": s_in, "sw": sw}
@@ -328,6 +342,7 @@ class Engine:
         # ---- bottleneck stages
         feats = []
         first_blocks = []
+        a_acts = {}
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
             f = 64 * 2 ** stage
             for block in range(nblocks):
@@ -335,10 +350,20 @@ class Engine:
                 st = 2 if (block == 0 and stage > 0) else 1
                 Hi, Wi = x.shape[1], x.shape[2]
                 Ho, Wo = (Hi - 1) // st + 1, (Wi - 1) // st + 1
-                a = buf(B, Ho, Wo, f)
-                ops.append(self._conv("res%s%s_branch2a" % (s, bname), [self._group(x, a, Ho, Wo)], B, stride=st, flags=L.CONV_RELU))
-                b2 = buf(B, Ho, Wo, f)
-                ops.append(self._conv("res%s%s_branch2b" % (s, bname), [self._group(a, b2, Ho, Wo)], B, pad=(1, 1), flags=L.CONV_RELU))
+                n2a, n2b = "res%s%s_branch2a" % (s, bname), "res%s%s_branch2b" % (s, bname)
+                if fp8_on and ("a", n2a) in self.fp8_scales:      # branch2a -> e4m3 -> fp8 branch2b -> bf16
+                    a = buf(B, Ho, Wo, f, dtype=torch.uint8)
+                    sa = self.fp8_scales[("a", n2a)]
+                    ops.append(("convq",) + self._conv(n2a, [self._group(x, a, Ho, Wo)], B, stride=st, flags=L.CONV_RELU)[1:] + (sa,))
+                    b2 = buf(B, Ho, Wo, f)
+                    ops.append(self._conv8(n2b, [self._group(a, b2, Ho, Wo)], B, sa, 1.0, out_fp8=False))
+                else:
+                    a = buf(B, Ho, Wo, f)
+                    ops.append(self._conv(n2a, [self._group(x, a, Ho, Wo)], B, stride=st, flags=L.CONV_RELU))
+                    b2 = buf(B, Ho, Wo, f)
+                    ops.append(self._conv(n2b, [self._group(a, b2, Ho, Wo)], B, pad=(1, 1), flags=L.CONV_RELU))
+                    if f >= 128:
+                        a_acts[n2a] = a
                 if block == 0:
                     sc = buf(B, Ho, Wo, 4 * f)
                     ops.append(self._conv("res%s%s_branch1" % (s, bname), [self._group(x, sc, Ho, Wo)], B, stride=st))
@@ -365,10 +390,19 @@ class Engine:
         ops.append(self._conv("C4_reduced", [self._group(C4, P4m, *hw(C4), res=P5r)], B, flags=L.CONV_RES_UPSAMPLE))
         P4 = buf(B, *hw(C4), 256)
         ops.append(self._conv("P4", [self._group(P4m, P4, *hw(C4))], B, pad=(1, 1)))
-        P3m = buf(B, *hw(C3), 256)
-        ops.append(self._conv("C3_reduced", [self._group(C3, P3m, *hw(C3), res=P4m)], B, flags=L.CONV_RES_UPSAMPLE))
-        P3 = buf(B, *hw(C3), 256)
-        ops.append(self._conv("P3", [self._group(P3m, P3, *hw(C3))], B, pad=(1, 1)))
+        p3_fp8 = fp8_on and ("a", "C3_reduced") in self.fp8_scales
+        if p3_fp8:        # P3's input has no other reader and P3 itself only feeds the towers: C3_reduced -> e4m3 -> fp8 P3 -> e4m3
+            s3 = self.fp8_scales[("a", "C3_reduced")]
+            P3m = buf(B, *hw(C3), 256, dtype=torch.uint8)
+            ops.append(("convq",) + self._conv("C3_reduced", [self._group(C3, P3m, *hw(C3), res=P4m)], B, flags=L.CONV_RES_UPSAMPLE)[1:] + (s3,))
+            P3 = buf(B, *hw(C3), 256, dtype=torch.uint8)
+            ops.append(self._conv8("P3", [self._group(P3m, P3, *hw(C3))], B, s3, self.fp8_scales["in"], out_fp8=True, relu=False))
+        else:
+            P3m = buf(B, *hw(C3), 256)
+            ops.append(self._conv("C3_reduced", [self._group(C3, P3m, *hw(C3), res=P4m)], B, flags=L.CONV_RES_UPSAMPLE))
+            P3 = buf(B, *hw(C3), 256)
+            ops.append(self._conv("P3", [self._group(P3m, P3, *hw(C3))], B, pad=(1, 1)))
+            a_acts["C3_reduced"] = P3m
         H6, W6 = (C5.shape[1] + 1) // 2, (C5.shape[2] + 1) // 2
         P6 = buf(B, H6, W6, 256)
         ops.append(self._conv("P6", [self._group(C5, P6, H6, W6)], B, stride=2,
@@ -391,9 +425,10 @@ class Engine:
         tower_ranges = []
         tower_acts = {}
         if fp8_on:                                       # the pyramid, quantised once for both towers
-            pyr8 = [buf(B, *hw(p), 256, dtype=torch.uint8) for p in pyr]
+            pyr8 = [p if p.dtype == torch.uint8 else buf(B, *hw(p), 256, dtype=torch.uint8) for p in pyr]
             for p, p8 in zip(pyr, pyr8):
-                ops.append(("quant", p, p8, self.fp8_scales["in"]))
+                if p8 is not p:
+                    ops.append(("quant", p, p8, self.fp8_scales["in"]))
         for prefix, out_t, per_anchor, last_flags in (("pyramid_regression", regression, 4, L.CONV_OUT_F32),
                                                       ("pyramid_classification", classification, self.K,
                                                        L.CONV_OUT_F32 | L.CONV_SIGMOID)):
@@ -432,7 +467,7 @@ class Engine:
                     v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
                 v = [op for op in v if op is not None]
                 variants[(fs, fd)] = (v, self._schedule(v))
-        plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
+        plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "a_acts": a_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
                 "boxes": torch.empty(B, L.RTN_MAX_DET, 4, dtype=torch.float32, device=dev),
@@ -446,7 +481,7 @@ class Engine:
     def _op_io(op):
         """(tensors read, tensors written) of a plan op, as data pointers."""
         kind = op[0]
-        if kind in ("conv", "conv8"):
+        if kind in ("conv", "conv8", "convq"):
             m = op[3]
             reads = [t.data_ptr() for t in m["xs"]] + [t.data_ptr() for t in m["res"] if t is not None]
             return reads, [t.data_ptr() for t in m["ys"]]
@@ -472,7 +507,7 @@ class Engine:
         run on side lanes so that their launch latency and partly filled last rounds of workgroups overlap other work."""
         if op[0] == "relu":
             return 1                                              # between P6 and P7
-        if op[0] not in ("conv", "conv8"):
+        if op[0] not in ("conv", "conv8", "convq"):
             return 0
         name = op[2]
         if name.endswith("_branch1") or name in ("P6", "P7"):
@@ -590,6 +625,8 @@ class Engine:
             h.check(lib.rtn_conv1x1_dual_fwd(h.raw, C.byref(op[1]), C.byref(op[3])))
         elif kind == "conv8":
             h.check(lib.rtn_conv2d_fp8_fwd(h.raw, C.byref(op[1]), C.byref(op[4])))
+        elif kind == "convq":
+            h.check(lib.rtn_conv2d_fwd_fp8out(h.raw, C.byref(op[1]), op[4]))
         elif kind == "quant":
             h.check(lib.rtn_quantize_fp8(h.raw, op[1].data_ptr(), self.rdt, op[2].data_ptr(), op[1].numel(), op[3]))
         elif kind == "stem":
