@@ -176,3 +176,50 @@ def test_preprocessing_kernels(M):
     r1 = P.resize_cubic(R.preprocess_custom_tf(want[:400, :500]), scales[1])
     c1 = canvas[1].cpu().numpy()
     assert np.abs(c1[:r1.shape[0], :r1.shape[1]] - r1).max() <= 1e-5 and np.all(c1[r1.shape[0]:] == 0) and np.all(c1[:, r1.shape[1]:] == 0)
+
+
+def test_config0_test_image_flow_on_a_sample_sized_page(M, tmp_path):
+    """BASELINE.json configs[0]: RetinaNet.py test() on ONE processed 3-channel page, batch 1 (RetinaNet.py:306-402), through the
+    mirror surface: preprocess_image('custom_tf') -> resize_image -> predict_on_batch(image[None]) -> boxes /= scale -> draw / crop /
+    write.  The reference's page is 2200x1712 (scale 0.46729 -> 1028x800, 155,331 anchors); a synthetic page of that size stands in
+    (the reference's file cannot travel to the GPU box).  Two weight sets: with the prior-probability bias no
+    score reaches the 0.6 drawing threshold and the "noDete" output is written; a zero bias gives detections, checked in fp32 against the float64 oracle at the
+    1e-3 px bar and written out as crops."""
+    from oracle.ref_net import RefNet
+    D, U = M.defineModel, M.utils
+    rng = np.random.RandomState(0)
+    base = np.clip(rng.exponential(12.0, (2200 // 8, 1712 // 8, 3)) * 6, 0, 255)
+    page = np.kron(base, np.ones((8, 8, 1))).astype(np.uint8)                    # smooth, heavy-tailed like the distance maps
+    image = U.preprocess_image(page, mode="custom_tf")
+    image, scale = U.resize_image(image)
+    assert image.shape == (1028, 800, 3) and abs(scale - 0.4672897196261682) < 1e-15
+    Wt = M.anchors._rt.weights
+    for cls_bias, expect_boxes in ((None, False), (0.0, True)):
+        m = D.Model("resnet50", 1, 9, dtype="f32")
+        m._state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=cls_bias, tame=True)
+        pm = D.retinanet_bbox(model=m)
+        boxes, scores, labels = pm.predict_on_batch(np.expand_dims(image, axis=0))
+        assert boxes.shape == (1, 300, 4) and scores.shape == (1, 300) and labels.shape == (1, 300)
+        reg, cls = m.predict_on_batch(np.expand_dims(image, axis=0))
+        assert reg.shape == (1, 155331, 4) and cls.shape == (1, 155331, 1)
+        out = tmp_path / ("bias_%s" % cls_bias)
+        draw = page.copy()
+        kept = U.render_detections(image, draw, boxes.copy(), scores, labels, scale, str(out), "sample_0717_023.jpg", score_threshold=0.6 if not expect_boxes else 0.5)
+        names = sorted(os.listdir(out / "detections_cropped"))
+        assert os.path.exists(out / "detections_inImage" / "sample_0717_023.jpg")
+        if not expect_boxes:
+            # nothing reaches the 0.6 the reference draws at (RetinaNet.py:373): one "noDete" file carrying the best score
+            assert np.all(scores < 0.6) and kept == [] and len(names) == 1 and "noDete_minScore-_%s" % scores[0, 0] in names[0]
+            continue
+        oreg, ocls = RefNet(m._state, dtype=torch.float64).forward(image[None])
+        a32 = R.anchors_f32((1028, 800, 3))
+        dbox = np.abs(R.decode_boxes_f32(a32, reg[0], (1028, 800)).astype(np.float64) -
+                      R.decode_boxes_f32(a32, oreg.numpy()[0].astype(np.float32), (1028, 800))).max()
+        dcls = np.abs(cls - ocls.numpy()).max()
+        print("config 0 page, fp32 path vs float64 oracle: box %.3e px, score %.3e" % (dbox, dcls))
+        assert dbox <= 1e-3 and dcls <= 1e-5
+        wb, ws, wl = R.filter_detections(R.decode_boxes_f32(a32, reg[0], (1028, 800)), cls[0])
+        assert np.array_equal(boxes[0], wb) and np.array_equal(scores[0], ws) and np.array_equal(labels[0], wl)
+        n = int((scores[0] >= 0.5).sum())
+        assert n > 0 and len(kept) == n and names == sorted("sample_0717_023_%d.jpg" % k for k in range(n))
+        assert all(np.array_equal(k[0], (boxes[0, i] / scale).astype(int)) for i, k in enumerate(kept))
