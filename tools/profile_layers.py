@@ -1,4 +1,5 @@
-"""Per-op device time of one forward pass at the bench configuration (events on the launch stream)."""
+"""Per-op device time of one forward pass at the bench configuration (events on the launch stream).
+  python tools/profile_layers.py [bf16|f32] [batch] [--fp8] [--backbone resnet101] [--canvas H W]"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,24 +7,33 @@ import torch
 import bench
 PKG = bench.PKG
 E = importlib.import_module(PKG + ".engine"); Wt = importlib.import_module(PKG + ".weights")
-dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BATCH
-state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=bench.CLS_BIAS, tame=True)
-eng = E.Engine("resnet50", 1, 9, dtype=dtype); eng.load_state(state)
-x = bench.synth_images(torch, B, 1000, "cuda")
+args = sys.argv[1:]
+fp8 = "--fp8" in args
+backbone = args[args.index("--backbone") + 1] if "--backbone" in args else "resnet50"
+canvas = tuple(int(v) for v in args[args.index("--canvas") + 1:args.index("--canvas") + 3]) if "--canvas" in args else bench.CANVAS
+pos = [a for i, a in enumerate(args) if not a.startswith("--") and not (i and args[i - 1] in ("--backbone", "--canvas")) and not (i > 1 and args[i - 2] == "--canvas")]
+dtype = pos[0] if len(pos) > 0 else "bf16"
+B = int(pos[1]) if len(pos) > 1 else bench.BATCH
+state = Wt.init_state(backbone, 1, 9, seed=0, randomize_bn=True, cls_bias=bench.CLS_BIAS, tame=True)
+eng = E.Engine(backbone, 1, 9, dtype=dtype); eng.load_state(state)
+if canvas == bench.CANVAS:
+    x = bench.synth_images(torch, B, 1000, "cuda")
+else:
+    x = (torch.rand(B, canvas[0], canvas[1], 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(torch.bfloat16).cuda()
 if dtype == "f32": x = x.float()
+if fp8: eng.calibrate_fp8(x, backbone=True)
 for _ in range(2): eng.detect(x)
 reps = 5
 per = eng.profile_ops(x, reps=reps)
-plan = eng._plan(B, *bench.CANVAS)
+plan = eng._plan(B, *canvas)
 tot = 0.0
 print("%-28s %9s %9s %8s  shape" % ("op", "ms", "GFLOP", "TFLOP/s"))
 for (kind, ms), op in zip(per, eng.active_ops(plan) + [("detect",)]):
     ms /= reps; tot += ms
-    if kind in ("conv", "dual"):
+    if kind in ("conv", "dual", "conv8", "convq"):
         d = op[1]; fl = bench.conv_flops(d, B)
         g = d.g[0]
-        print("%-28s %9.4f %9.2f %8.1f  M=%d N=%d K=%d k%dx%d s%d groups=%d" % (op[2], ms, fl / 1e9, fl / ms / 1e9,
+        print("%-28s %9.4f %9.2f %8.1f  M=%d N=%d K=%d k%dx%d s%d groups=%d" % (op[2] + {"conv8": " [fp8]", "convq": " [>fp8]"}.get(kind, ""), ms, fl / 1e9, fl / ms / 1e9,
               sum(d.g[i].Hout * d.g[i].Wout for i in range(d.ngroups)) * B, d.N, d.KH * d.KW * d.Crun, d.KH, d.KW, d.sy, d.ngroups))
     else:
         print("%-28s %9.4f" % (kind, ms))
