@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtn.so")
+LIB_PATH = os.environ.get("RTN_LIB_PATH") or os.path.join(_HERE, "librtn.so")      # RTN_LIB_PATH: A/B two builds on one box
 
 RTN_BF16, RTN_F32, RTN_U8, RTN_FP8 = 0, 1, 2, 3
 RTN_MAX_GROUPS, RTN_MAX_GT, RTN_MAX_DET = 5, 64, 300
