@@ -435,18 +435,29 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const
     int cur = 0;
 #pragma unroll 1
     for (int tile = tlo; tile < thi; ++tile) {
+        const char* A = lds + cur * 2 * WD_TILE_B;     // dY tile
+        const char* B = A + WD_TILE_B;                 // X tile
+        // the tile's first A fragments are requested before the next tile's staging is issued (as in the forward kernels)
+        s16x8 af0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;
+            const int aoff = (8 * g + q) * WD_ROWB + (((ca >> 5) ^ rkey) << 5) + (ca & 31);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WD_ROWB));
+            af0[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
         if (tile + 1 < thi) {
             WD_STAGE(tile + 1, cur ^ 1);
             WD_ROWINFO(tile + 2);
         }
-        const char* A = lds + cur * 2 * WD_TILE_B;     // dY tile
-        const char* B = A + WD_TILE_B;                 // X tile
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int row = 32 * s + 8 * g + q;
             s16x8 af[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (s == 0) { af[i] = af0[i]; continue; }
                 const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;            // byte column inside the 512-byte row
                 const int aoff = row * WD_ROWB + (((ca >> 5) ^ rkey) << 5) + (ca & 31);
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
