@@ -1382,10 +1382,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         bn2 = d->N > 128 ? 256 : 128;
     }
     if (impl == 3 && !halo_ok) impl = 2;
-    // measured (tools/ab_conv.py, RTN_CONV_HALO=0|1): +3..4 % on the 256-channel 3x3 layers (heads, P3, P4, res4), none or a
-    // small loss below that, so the narrower layers stay on the per-tap kernel.  RTN_CONV_HALO=2 forces it wherever it applies.
+    // measured (tools/ab_conv.py): with 256-wide tiles (the grouped head layers) the halo kernel and the per-tap kernel are level
+    // (0.2113 vs 0.2116 ms) and the halo kernel stays; with the 64-wide tiles the cost model gives the single-group layers
+    // (res4/res5 3x3, P3, P4) the per-tap kernel is 1-10 % faster since both request their first fragments ahead of the staging
+    // issue (res5 3x3 0.0749 vs 0.0821 ms, res4 0.0609 vs 0.0634), so those went back to it.  RTN_CONV_HALO=2 forces the halo
+    // kernel wherever it applies, 0 disables it.
     const int halo_env = rtn_env_int("RTN_CONV_HALO", 1);
-    if (impl == 2 && halo_ok && rtn_conv_impl_override() == 0 && (halo_env == 2 || (halo_env == 1 && d->N >= 256))) impl = 3;
+    if (impl == 2 && halo_ok && rtn_conv_impl_override() == 0 && (halo_env == 2 || (halo_env == 1 && d->N >= 256 && bn2 == 256))) impl = 3;
     const int TM = impl == 3 ? BM2 - (d->KW - 1) : (impl == 2 ? BM2 : BM);
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
