@@ -11,6 +11,8 @@ x = bench.synth_images(torch, bench.BATCH, 1000, "cuda")
 eng.detect(x); torch.cuda.synchronize()
 plan = eng._plan(bench.BATCH, *bench.CANVAS)
 ops = {op[2]: op for op in plan["ops"] if op[0] == "conv"}
+if layers == ["all"]:
+    layers = [n for n in ops if n != "conv1"]
 KNOBS = sorted({k for v in variants for k in v})
 for name in layers:
     op = ops[name]; fl = bench.conv_flops(op[1], bench.BATCH)
