@@ -181,7 +181,8 @@ class Engine:
         five pyramid levels of a bf16 forward pass of `images`; weights one scale per layer.  The towers' first input is the
         quantised pyramid, their last layer writes bf16 for the (bf16) output convs.  backbone=True also runs every 3x3 branch2b
         layer with >= 128 channels in fp8: its producer branch2a writes e4m3 straight from its epilogue (rtn_conv2d_fwd_fp8out),
-        branch2b writes bf16 for the 1x1 branch2c.  calibrate_fp8(None) switches back."""
+        branch2b writes bf16 for the 1x1 branch2c.  `images` may be a list of batches (scales from the maximum over all of
+        them); calibrate_fp8(None) switches back."""
         self.fp8_scales = None
         self.fp8_backbone = bool(backbone) and images is not None
         self.plans = {k: v for k, v in self.plans.items() if not k[3]}     # bf16 plans (and a trainer's view of them) stay valid
@@ -189,22 +190,25 @@ class Engine:
             return None
         if self.dtype != "bf16":
             raise ValueError("fp8 towers extend the bf16 engine")
-        B, H, W, _ = images.shape
-        self.forward(images)
-        torch.cuda.synchronize(self.device)
-        plan = self._plan(B, H, W)
+        batches = list(images) if isinstance(images, (list, tuple)) else [images]     # several batches: the maximum over all
+        amax = {}
 
-        def scale_of(tensors):
-            amax = max(float(t.float().abs().max()) for t in tensors)
-            return 448.0 / (margin * max(amax, 1e-20))
+        def see(key, tensors):
+            amax[key] = max([amax.get(key, 0.0)] + [float(t.float().abs().max()) for t in tensors])
 
-        scales = {"in": scale_of(plan["pyr"])}
-        for prefix, acts in plan["tower_acts"].items():
-            for i, levels in enumerate(acts):
-                scales[(prefix, i)] = scale_of(levels)
-        if self.fp8_backbone:
-            for name, a in plan["a_acts"].items():
-                scales[("a", name)] = scale_of([a])
+        for x in batches:
+            B, H, W, _ = x.shape
+            self.forward(x)
+            torch.cuda.synchronize(self.device)
+            plan = self._plan(B, H, W)
+            see("in", plan["pyr"])
+            for prefix, acts in plan["tower_acts"].items():
+                for i, levels in enumerate(acts):
+                    see((prefix, i), levels)
+            if self.fp8_backbone:
+                for name, a in plan["a_acts"].items():
+                    see(("a", name), [a])
+        scales = {k: 448.0 / (margin * max(v, 1e-20)) for k, v in amax.items()}
         self.fp8_scales = scales
         return scales
 

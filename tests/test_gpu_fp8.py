@@ -268,5 +268,11 @@ def test_fp8_backbone_layers_against_bf16_engine(pkg):
     # stated tolerance with 22 fp8 layers on seeded random filters (each adds ~5 % to its branch; the residual stream dilutes the
     # backbone's share; measured 6.1 % / 0.063): box deltas <= 10 % relative RMS, scores <= 0.10
     assert torch.isfinite(reg1).all() and rel_rms <= 0.10 and dcls <= 0.10
+    # several calibration batches: every scale is the minimum (largest range) of the single-batch scales
+    x2 = (torch.rand(1, 160, 192, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    s1 = eng.calibrate_fp8(x, backbone=True)
+    s2 = eng.calibrate_fp8(x2, backbone=True)
+    s12 = eng.calibrate_fp8([x, x2], backbone=True)
+    assert set(s12) == set(s1) and all(abs(s12[k] - min(s1[k], s2[k])) <= 1e-6 * s12[k] for k in s1)
     eng.calibrate_fp8(None)
     assert not eng.fp8_backbone and torch.equal(eng.forward(x)[0], reg0)

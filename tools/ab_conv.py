@@ -11,11 +11,13 @@ x = bench.synth_images(torch, bench.BATCH, 1000, "cuda")
 eng.detect(x); torch.cuda.synchronize()
 plan = eng._plan(bench.BATCH, *bench.CANVAS)
 ops = {op[2]: op for op in plan["ops"] if op[0] == "conv"}
+ops.update({op[2]: op for op in eng.active_ops(plan) if op[0] == "dual"})        # e.g. res2a_branch2c+1 (folded shortcut)
 if layers == ["all"]:
     layers = [n for n in ops if n != "conv1"]
 KNOBS = sorted({k for v in variants for k in v})
 for name in layers:
     op = ops[name]; fl = bench.conv_flops(op[1], bench.BATCH)
+    if op[0] == "dual": eng._dual_weights()
     times = {i: [] for i in range(len(variants))}
     for rnd in range(12):
         for i, v in enumerate(variants):
