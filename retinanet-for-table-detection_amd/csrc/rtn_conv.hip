@@ -1378,8 +1378,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (s2) impl = 2;                                  // only the 256-row per-tap kernel walks a second source
     if (q8) {                                          // fp8 exists in the halo kernel only
         if (!halo_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8: only stride-1 'same' KHxKW (KW 2..4) layers over dense NHWC inputs with whole 128-byte channel chunks");
-        impl = 3;
-        bn2 = d->N > 128 ? 256 : 128;
+        impl = 3;                                      // tile width: the cost model's choice above, as for bf16
     }
     if (impl == 3 && !halo_ok) impl = 2;
     // measured (tools/ab_conv.py): with 256-wide tiles (the grouped head layers) the halo kernel and the per-tap kernel are level
@@ -1575,7 +1574,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         }                                                                                                \
         hipLaunchKernelGGL((conv_igemm3_kernel<E, B>), gdim, bdim, ldsb, h->stream, p);                  \
     } while (0)
-        if (es == 1) { if (BN == 128) RTN_L3(1, 128); else RTN_L3(1, 256); }
+        if (es == 1) { if (BN == 64) RTN_L3(1, 64); else if (BN == 128) RTN_L3(1, 128); else RTN_L3(1, 256); }
         else if (es == 2) { if (BN == 64) RTN_L3(2, 64); else if (BN == 128) RTN_L3(2, 128); else RTN_L3(2, 256); }
         else         { if (BN == 64) RTN_L3(4, 64); else if (BN == 128) RTN_L3(4, 128); else RTN_L3(4, 256); }
 #undef RTN_L3
