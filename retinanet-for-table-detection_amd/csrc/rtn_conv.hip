@@ -629,7 +629,7 @@ constexpr int NT2 = 512;
 
 template <int ES, int BN, bool IL, bool DUAL = false>
 __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
-    constexpr int ESH = (ES == 2) ? 1 : 2;
+    constexpr int ESH = (ES == 1) ? 0 : ((ES == 2) ? 1 : 2);
     constexpr int WN = BN / 2;
     constexpr int NI = WN / 16;
     constexpr int MI = 4;
@@ -831,6 +831,24 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) RTN_DMA(nxt, d);
         }
+        if constexpr (ES == 1) {                      // fp8: both 16-byte halves of a row feed ONE K = 128 instruction (see mma_step_fp8)
+            uint4 a1_[MI];
+#pragma unroll
+            for (int i_ = 0; i_ < MI; ++i_) a1_[i_] = *reinterpret_cast<const uint4*>(A_ + i_ * 16 * 128 + rd1);
+#pragma unroll
+            for (int jh = 0; jh < NI; jh += NJ) {
+                uint4 b0_[NJ], b1_[NJ];
+#pragma unroll
+                for (int j_ = 0; j_ < NJ; ++j_) {
+                    b0_[j_] = jh == 0 ? pb_[j_] : *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rd0);
+                    b1_[j_] = *reinterpret_cast<const uint4*>(B_ + (jh + j_) * 16 * 128 + rd1);
+                }
+#pragma unroll
+                for (int i_ = 0; i_ < MI; ++i_)
+#pragma unroll
+                    for (int j_ = 0; j_ < NJ; ++j_) mma_step_fp8(acc[i_][jh + j_], pa_[i_], a1_[i_], b0_[j_], b1_[j_]);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int rd = ks ? rd1 : rd0;
@@ -925,7 +943,8 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
             const float4 v0 = *reinterpret_cast<const float4*>(sp);
             const float4 v1 = *reinterpret_cast<const float4*>(sp + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
+            if constexpr (ES == 1) epilogue_fp8(p, G, rows[it], n, v, bv);
+            else epilogue_finish8<ES>(p, G, rows[it], Wout, n, v, bv, res_vec, pre[it]);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);      // reads done before the next half overwrites the slice
     }
@@ -1376,9 +1395,9 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             s.in_img_stride != (long long)s.Hin * s.in_row_stride) halo_ok = false;
     }
     if (s2) impl = 2;                                  // only the 256-row per-tap kernel walks a second source
-    if (q8) {                                          // fp8 exists in the halo kernel only
+    if (q8) {                                          // fp8 layers: the shapes the halo kernel accepts (either kernel runs them)
         if (!halo_ok) return rtn_fail(h, RTN_EINVAL, "conv fp8: only stride-1 'same' KHxKW (KW 2..4) layers over dense NHWC inputs with whole 128-byte channel chunks");
-        impl = 3;                                      // tile width: the cost model's choice above, as for bf16
+        impl = bn2 == 256 ? 3 : 2;                     // as for bf16: halo kernel with 256-wide tiles, per-tap kernel below
     }
     if (impl == 3 && !halo_ok) impl = 2;
     // measured (tools/ab_conv.py): with 256-wide tiles (the grouped head layers) the halo kernel and the per-tap kernel are level
@@ -1629,7 +1648,8 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             if (es == 2) { if (BN == 64) RTN_L2D(2, 64); else if (BN == 128) RTN_L2D(2, 128); else RTN_L2D(2, 256); }
             else         { if (BN == 64) RTN_L2D(4, 64); else if (BN == 128) RTN_L2D(4, 128); else RTN_L2D(4, 256); }
         } else
-        if (es == 2) { if (BN == 64) RTN_L2(2, 64); else if (BN == 128) RTN_L2(2, 128); else RTN_L2(2, 256); }
+        if (es == 1) { if (BN == 64) RTN_L2K(1, 64, false); else if (BN == 128) RTN_L2K(1, 128, false); else RTN_L2K(1, 256, false); }
+        else if (es == 2) { if (BN == 64) RTN_L2(2, 64); else if (BN == 128) RTN_L2(2, 128); else RTN_L2(2, 256); }
         else         { if (BN == 64) RTN_L2(4, 64); else if (BN == 128) RTN_L2(4, 128); else RTN_L2(4, 256); }
 #undef RTN_L2D
 #undef RTN_L2
