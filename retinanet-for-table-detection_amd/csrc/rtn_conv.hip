@@ -1482,7 +1482,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     int BN = impl >= 2 ? bn2 : (d->N <= 64 ? 64 : 128);
     if (impl >= 2) {
         const int bn_env = rtn_env_int("RTN_CONV_BN2", 0);   // A/B override of the 256-row kernel's tile width
-        if (!q8 && (bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
+        if ((bn_env == 64 || bn_env == 128 || bn_env == 256) && bn_env <= ((d->N + 63) / 64) * 64) BN = bn_env;
     }
     p.w = (const char*)d->w;
     p.bias = d->bias;

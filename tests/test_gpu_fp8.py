@@ -115,6 +115,25 @@ def test_fp8_conv_bf16_output(pkg, handle, levels, cin, cout, k, relu):
         assert float((got - w).abs().max()) <= 1e-2 * scale, float((got - w).abs().max()) / scale
 
 
+@pytest.mark.parametrize("env", [{"RTN_CONV_BN2": "256", "RTN_CONV_HALO": "2"}, {"RTN_CONV_BN2": "128", "RTN_CONV_HALO": "2"},
+                                 {"RTN_CONV_BN2": "64", "RTN_CONV_HALO": "2"}, {"RTN_CONV_BN2": "256"}, {"RTN_CONV_BN2": "128"}])
+def test_fp8_conv_every_kernel_instance(pkg, handle, env, monkeypatch):
+    """The small test shapes all land on the per-tap kernel's 64-wide tile; the knobs force the other instances the selection
+    uses on large grids: halo kernel 256 / 128 / 64 wide (RTN_CONV_HALO=2) and per-tap kernel 256 / 128 wide."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for out_fp8 in (False, True):
+        outs, wants, so = run_fp8(pkg, handle, [(25, 42), (13, 21), (7, 11)], 256, 256, 3, True, out_fp8=out_fp8, seed=5)
+        for o, w in zip(outs, wants):
+            if out_fp8:
+                want = to_f8(w.float(), so)
+                dist = code_distance(o.cpu(), want.view(torch.uint8))
+                absdiff = (o.cpu().view(F8).float() - want.float()).abs()
+                assert bool(((dist <= 1) | (absdiff <= 1e-4 * 448.0)).all()) and float((dist > 0).float().mean()) < 0.01
+            else:
+                assert float((o.double().cpu() - w).abs().max()) <= 1e-2 * float(w.abs().max())
+
+
 @pytest.mark.parametrize("levels,cin,cout,relu", [
     ([(19, 23)], 256, 256, True),
     ([(25, 42), (13, 21), (7, 11)], 256, 256, True),
