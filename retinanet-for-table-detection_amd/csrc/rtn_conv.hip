@@ -109,6 +109,7 @@ struct KParams {
     int dense_out;   // out/res/mask are plain [M][ld] matrices: the epilogue needs no (image, pixel) split
     int dense_in;    // 1x1, stride 1, no padding on a contiguous NHWC input: row m starts at m * pix_stride
     int nstages;     // 256-row kernel: depth of the LDS staging ring (1..4), sized by the launcher
+    int taps_uniform;  // every 128-byte K row lies inside one tap (Crun * element size is a multiple of 128)
     // second input of a K-concatenated 1x1 layer (rtn_conv1x1_dual_fwd): K steps >= nkt1 read `in2` (group 0 only)
     const char* in2;
     unsigned in2_bytes;
@@ -732,13 +733,17 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm2_kernel(const KParams p) {
 #define RTN_TAPS(KT)                                                                                                \
     const bool src2_ = DUAL && (KT) >= p.nkt1;                                                                      \
     const unsigned delta2_ = (unsigned)(((KT) - p.nkt1) * 128 + c * 16);                                            \
-    const int kb_ = (KT) * 128 + c * 16;   /* KT = position of the step in K (see KOrder) */                        \
+    /* KT = position of the step in K (see KOrder).  When a tap spans whole 128-byte chunks (every layer but the packed   \
+       stem) the tap of a step is the same for all lanes: decoded from the uniform KT on the scalar unit, the lane's     \
+       16-byte piece added at the end; otherwise (two taps per row) the decode stays per lane. */                        \
+    const int kb_ = (KT) * 128 + (p.taps_uniform ? 0 : c * 16);                                                     \
     const int k0_ = kb_ >> ESH;                                                                                     \
     const int kpos_ = k0_ >> p.cshift;                                                                              \
     const int coff_ = k0_ & p.crun_mask;                                                                            \
     const int kh_ = (kpos_ * p.kw_inv) >> 16;                                                                       \
     const int kw_ = kpos_ - kh_ * p.KW;                                                                             \
-    const unsigned delta_ = (unsigned)(kh_ * in_row_stride_b + kw_ * p.pix_stride_b + coff_ * ES);                  \
+    const unsigned delta_ = (unsigned)(kh_ * in_row_stride_b + kw_ * p.pix_stride_b + coff_ * ES) +                 \
+                            (p.taps_uniform ? (unsigned)c * 16u : 0u);                                              \
     const unsigned wk_ = wbase + (unsigned)(KT) * 128u;
 #define RTN_DMA(BUF, D)                                                                                             \
     {                                                                                                               \
@@ -1504,6 +1509,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         p.in2_step = s2->step;
     }
     p.crun_mask = d->Crun - 1;
+    p.taps_uniform = ((long long)d->Crun * es) % 128 == 0 ? 1 : 0;
     p.KW = d->KW;
     p.KH = d->KH;
     p.kw_inv = (65536 + d->KW - 1) / d->KW;
