@@ -1,3 +1,5 @@
+"""Where the fp8 convolution differs from the float64 reference of the same e4m3 bytes: the elements more than one code apart
+(all near zero) and the accumulate noise floor in units of the output scale (cited by tests/test_gpu_fp8.py)."""
 import importlib, sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import test_gpu_fp8 as T
