@@ -126,8 +126,18 @@ typedef struct {
     int32_t out_ld;          /* elements per output pixel (= N for NHWC; 4*A / K*A for
                                 the head outputs)                                      */
     int32_t flags;
+    int32_t reserved_;
+    void*   workspace;       /* caller-owned scratch for the launches that split a K loop over workgroups (f32 partial-sum
+                                slabs of the split-K and tail-split paths), >= rtn_conv2d_workspace_bytes(h, d) bytes,
+                                16-byte aligned, used only while the launch runs: launches that may overlap in time (other
+                                streams) need different buffers.  NULL / too small = no K split for this launch (slower on
+                                the few layers that want one, same results up to f32 summation order).  */
+    int64_t workspace_bytes;
 } rtn_conv_desc_t;
 
+/* Bytes of `workspace` the launch described by `d` can use on this device (0 for most layers).  The library never allocates:
+ * every forward / dgrad entry point below takes its scratch from the descriptor. */
+size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
 
 /* Two 1x1 convolutions that are ADDED, as one GEMM over the concatenated K: out = W1 . in + W2 . in2[stepped] + bias (+ the

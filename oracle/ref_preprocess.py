@@ -13,6 +13,8 @@ data/orig/sample_0717_023_orig.jpg -> data/processed/sample_0717_023.jpg, checke
   imwrite(float image)   saturate_cast<uchar>: round half to even, clamp to [0,255]
   resize(INTER_CUBIC)    a = -0.75, src = (dst + 0.5) / scale - 0.5, replicate border, float32 separable
 """
+import math
+
 import numpy as np
 
 F32 = np.float32
@@ -28,9 +30,13 @@ def bgr2gray(img):
 def gaussian_kernel(n=11, sigma=-1.0):
     if sigma <= 0:
         sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8
-    x = np.arange(n, dtype=np.float64) - (n - 1) * 0.5
-    k = np.exp(-0.5 / (sigma * sigma) * x * x)
-    return (k / k.sum()).astype(F32)
+    # cv::getGaussianKernel: taps exp(-x^2 / (2 sigma^2)) in double, summed in tap order, divided, stored as float.  libm's exp
+    # and a sequential sum (not numpy's vectorised exp / pairwise sum) so that the taps do not depend on the host's SIMD level.
+    k = [math.exp(-0.5 / (sigma * sigma) * (i - (n - 1) * 0.5) ** 2) for i in range(n)]
+    total = 0.0
+    for v in k:
+        total += v
+    return np.array([v / total for v in k], dtype=np.float64).astype(F32)
 
 
 def adaptive_threshold_gaussian(gray, block=11, c=2):

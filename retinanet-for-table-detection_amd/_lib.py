@@ -51,6 +51,7 @@ class ConvDesc(C.Structure):
         ("w_rows", C.c_int32), ("N", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
         ("Crun", C.c_int32), ("pix_stride", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
         ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("out_ld", C.c_int32), ("flags", C.c_int32),
+        ("reserved_", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "rtn_set_stream": (_I, [_P, _P]),
     "rtn_last_error": (C.c_char_p, [_P]),
     "rtn_version": (C.c_char_p, []),
+    "rtn_conv2d_workspace_bytes": (_SZ, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
@@ -186,6 +188,19 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+
+def attach_conv_workspace(handle, d):
+    """Give a conv descriptor the scratch rtn_conv2d_workspace_bytes() asks for on this device: a uint8 device tensor kept alive
+    by the descriptor (the library never allocates; the K-split paths are skipped without it).  One buffer per descriptor, so
+    launches on different streams never share scratch.  Returns the tensor or None."""
+    n = int(lib.rtn_conv2d_workspace_bytes(handle.raw, C.byref(d)))
+    if n <= 0:
+        d.workspace, d.workspace_bytes, d._ws = None, 0, None
+        return None
+    t = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", handle.device))
+    d.workspace, d.workspace_bytes, d._ws = t.data_ptr(), n, t
+    return t
 
 
 def generate_anchors_f64(base_size, ratios, scales):

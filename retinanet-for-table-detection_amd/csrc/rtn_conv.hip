@@ -1296,8 +1296,11 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// `query` != nullptr: no launch; *query = bytes of d->workspace this launch can use (the K-split paths below).
+static constexpr long long kMaxConvWorkspace = 256ll << 20;
 static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2 = nullptr, const rtn_conv_fp8_t* q8 = nullptr,
-                       float out8_scale = 0.f) {
+                       float out8_scale = 0.f, size_t* query = nullptr) {
+    if (query) *query = 0;
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32 && !(d->dtype == RTN_FP8 && q8)) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
@@ -1349,6 +1352,9 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if ((d->flags & RTN_CONV_RES_SAME) && (d->flags & RTN_CONV_RES_UPSAMPLE))
         return rtn_fail(h, RTN_EINVAL, "conv: both residual modes set");
     const bool has_res = d->flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE);
+    // caller-owned scratch of the K-split paths (never allocated here)
+    float* const ws_ptr = (!query && d->workspace && !((uintptr_t)d->workspace & 15) && d->workspace_bytes > 0) ? (float*)d->workspace : nullptr;
+    const long long ws_cap = query ? kMaxConvWorkspace : (ws_ptr ? (long long)d->workspace_bytes : 0);
 
     KParams p;
     memset(&p, 0, sizeof(p));
@@ -1558,8 +1564,9 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             const int per = (int)((units + S - 1) / S);
             S = (units + per - 1) / per;
             const long long slab_bytes = rest * S * (long long)BM2 * BN * 4;
-            float* scratch = S >= 2 ? rtn_splitk_scratch(h) : nullptr;
-            if (scratch && slab_bytes <= (long long)h->splitk_bytes) {
+            if (query && S >= 2 && slab_bytes <= ws_cap) { *query = (size_t)slab_bytes; return RTN_OK; }
+            float* scratch = S >= 2 ? ws_ptr : nullptr;
+            if (scratch && slab_bytes <= ws_cap) {
                 tail_tiles = (int)rest;
                 p.tail_mode = 1;
                 p.tail_main = (int)(grid - rest);
@@ -1571,6 +1578,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             }
         }
     }
+    if (query && impl >= 2) return RTN_OK;
     for (int pass = 0; pass < (tail_tiles ? 2 : 1); ++pass) {
     if (pass == 1) {                                   // the finish launch: one workgroup per tail tile
         RTN_CHECK_LAUNCH(h, "conv (tail-split main launch)");
@@ -1663,6 +1671,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     }
     }   // pass
     if (impl < 2) {
+        if (query && !(d->ngroups == 1 && grid < 128 && p.nkt >= 16)) return RTN_OK;
         dim3 bdim(NT);
         // split-K: a long K loop on a grid that cannot fill the chip (P6: 36 workgroups x 288 K steps)
         int ksplit = 1;
@@ -1672,12 +1681,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             if (ksplit > p.nkt / 4) ksplit = p.nkt / 4;
             if (ksplit_env > 1) ksplit = ksplit_env < p.nkt ? ksplit_env : p.nkt;
             const long long slab = (long long)p.g[0].M * (((d->N + 7) / 8) * 8) * 4;
-            while (ksplit > 1 && slab * ksplit > (long long)h->splitk_bytes) --ksplit;
+            while (ksplit > 1 && slab * ksplit > ws_cap) --ksplit;
             if (ksplit >= 2) {                                   // every slice must own at least one K step (it writes its whole slab)
                 const int per = (p.nkt + ksplit - 1) / ksplit;
                 ksplit = (p.nkt + per - 1) / per;
             }
-            float* scratch = ksplit >= 2 ? rtn_splitk_scratch(h) : nullptr;
+            if (query) { if (ksplit >= 2) *query = (size_t)(slab * ksplit); return RTN_OK; }
+            float* scratch = ksplit >= 2 ? ws_ptr : nullptr;
             if (ksplit < 2 || !scratch) ksplit = 1;
             p.scratch = scratch;
         }
@@ -1708,6 +1718,14 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
 }
 
 extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) { return conv_launch(h, d); }
+
+extern "C" size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d) {
+    size_t n = 0;
+    if (!h || !d) return 0;
+    // the K-split paths are taken by plain forward / dgrad launches only (not by the dual-source or fp8 variants)
+    if (conv_launch(h, d, nullptr, nullptr, 0.f, &n) != RTN_OK) return 0;
+    return n;
+}
 
 extern "C" int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2) {
     if (!h) return RTN_EINVAL;

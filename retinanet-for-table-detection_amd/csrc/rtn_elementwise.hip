@@ -15,19 +15,16 @@ extern "C" int rtn_create(rtn_handle_t* out, int device) {
     if (!h) return RTN_ENOMEM;
     memset(h, 0, sizeof(*h));
     h->device = device;
-    h->splitk_bytes = 64u << 20;
     hipDeviceProp_t prop;
     const char* what = "hipSetDevice";
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) { what = "hipMalloc(zero page)"; e = hipMalloc(&h->zero_page, 256); }
     if (e == hipSuccess) { what = "hipMemset(zero page)"; e = hipMemset(h->zero_page, 0, 256); }
-    if (e == hipSuccess) { what = "hipMalloc(split-K scratch)"; e = hipMalloc((void**)&h->scratch[0].ptr, h->splitk_bytes); }
     if (e == hipSuccess) { what = "hipGetDeviceProperties"; e = hipGetDeviceProperties(&prop, device); }
     if (e != hipSuccess) {
         snprintf(g_create_err, sizeof(g_create_err), "%s on device %d: %s", what, device, hipGetErrorString(e));
         (void)hipGetLastError();
         if (h->zero_page) (void)hipFree(h->zero_page);
-        if (h->scratch[0].ptr) (void)hipFree(h->scratch[0].ptr);
         delete h;
         return RTN_EHIP;
     }
@@ -39,8 +36,6 @@ extern "C" int rtn_create(rtn_handle_t* out, int device) {
 extern "C" int rtn_destroy(rtn_handle_t h) {
     if (!h) return RTN_EINVAL;
     if (h->zero_page) (void)hipFree(h->zero_page);
-    for (int i = 0; i < rtn_ctx::kScratchSlots; ++i)
-        if (h->scratch[i].ptr) (void)hipFree(h->scratch[i].ptr);
     delete h;
     return RTN_OK;
 }

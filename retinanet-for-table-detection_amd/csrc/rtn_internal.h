@@ -10,12 +10,6 @@ struct rtn_ctx {
     int device;
     hipStream_t stream;
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
-    // f32 slabs for split-K partial sums: library-owned scratch, 64 MiB PER STREAM that uses split-K (launches on different
-    // streams may overlap in time, so each stream gets its own slabs; slot 0 is allocated at create and belongs to the first
-    // stream that needs one, further slots are allocated on first use)
-    static constexpr int kScratchSlots = 8;
-    struct { hipStream_t stream; float* ptr; bool used; } scratch[kScratchSlots];
-    size_t splitk_bytes;
     int num_cus;
     char err[512];
 };
@@ -27,24 +21,6 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
         va_end(ap);
     }
     return code;
-}
-
-// Scratch slabs of the handle's current stream, or nullptr (then the caller runs without split-K).
-inline float* rtn_splitk_scratch(rtn_ctx* h) {
-    for (int i = 0; i < rtn_ctx::kScratchSlots; ++i)
-        if (h->scratch[i].used && h->scratch[i].stream == h->stream) return h->scratch[i].ptr;
-    for (int i = 0; i < rtn_ctx::kScratchSlots; ++i) {
-        if (h->scratch[i].used) continue;
-        if (!h->scratch[i].ptr && hipMalloc((void**)&h->scratch[i].ptr, h->splitk_bytes) != hipSuccess) {
-            h->scratch[i].ptr = nullptr;
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        h->scratch[i].used = true;
-        h->scratch[i].stream = h->stream;
-        return h->scratch[i].ptr;
-    }
-    return nullptr;
 }
 
 #define RTN_HIP(h, call)                                                                   \

@@ -87,6 +87,7 @@ class Engine:
         self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
         self.fuse_shortcut = os.environ.get("RTN_FUSE_SHORTCUT", "1") != "0"  # inference: branch1 folded into branch2c (dual-source GEMM)
         self.weights_version = 0
+        self.load_epoch = 0            # bumped by load_state(): a live Trainer re-derives its master copy / plans from it
         self._dual, self._dual_version = {}, -1
         self._side = None
         self.fp8_scales = None         # set by calibrate_fp8(): the head towers then run in fp8 (inference, bf16 engine)
@@ -123,6 +124,7 @@ class Engine:
             self.w[name] = (wv, bv, kh, kw, cin, cout)
         self.plans = {}
         self.weights_version += 1
+        self.load_epoch += 1
 
     def _dual_weights(self):
         """K-concatenated filters of every stage's first block: [branch2c | branch1] along K, biases summed
@@ -264,6 +266,7 @@ class Engine:
         d.pad_t, d.pad_l = pad
         d.out_ld = cout if out_ld is None else out_ld
         d.flags = flags
+        L.attach_conv_workspace(self.h, d)                 # split-K / tail-split slabs (P6, P7, res4-sized grids): caller-owned
         meta = {"name": name, "xs": [g._x for g in groups], "ys": [g._out for g in groups], "res": [g._res for g in groups],
                 "offs": [g._off for g in groups], "stride": stride, "pad": pad, "flags": flags,
                 "relu": bool(flags & L.CONV_RELU), "kh": kh, "kw": kw, "cin": cin, "cout": cout, "B": B,
@@ -562,7 +565,10 @@ class Engine:
         """images: device tensor (B,H,W,3), float32 / bfloat16 (already normalised) or uint8 (raw 3-channel
         distance-transform page: the x/127.5-1 of model/utils.py:43-46 is fused into the stem packer).
         Returns device tensors regression (B,N,4) f32, classification (B,N,K) f32 — the training
-        model's outputs in the reference's order (model/defineModel.py:244-249)."""
+        model's outputs in the reference's order (model/defineModel.py:244-249).
+        The returned tensors are the plan's OWN output buffers for this (B,H,W): the next forward()/detect() call with the
+        same shape overwrites them (no allocation per step).  Clone what must outlive the next call
+        (Model.predict_on_batch copies to the host)."""
         if images.device.type != "cuda" or images.dim() != 4 or images.shape[3] != 3:
             raise ValueError("images must be a (B,H,W,3) tensor on the GPU")
         if images.dtype not in _SRC_DT:
@@ -676,7 +682,8 @@ class Engine:
         return [(op[0], totals[i]) for i, op in enumerate(ops)] + [("detect", totals[-1])]
 
     def detect(self, images, score_threshold=0.05, nms_threshold=0.5, max_detections=300):
-        """Inference model outputs [boxes (B,300,4), scores (B,300), labels (B,300)] (model/defineModel.py:310-315)."""
+        """Inference model outputs [boxes (B,300,4), scores (B,300), labels (B,300)] (model/defineModel.py:310-315).
+        Views of the plan's output buffers: overwritten by the next call with the same (B,H,W) - clone to keep them."""
         reg, cls = self.forward(images)
         B, H, W, _ = images.shape
         plan = self._plan(B, H, W)

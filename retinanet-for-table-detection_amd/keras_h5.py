@@ -474,20 +474,55 @@ class _Writer:
 _PARAM_ORDER = ["kernel", "bias", "gamma", "beta", "moving_mean", "moving_variance"]
 
 
+# The two head stacks are nested keras.models.Model instances (model/defineModel.py:78-167: names 'classification_submodel' /
+# 'regression_submodel'): Keras stores a nested model as ONE top-level layer whose weights keep their inner layer names.
+_SUBMODELS = (("pyramid_regression", "regression_submodel"), ("pyramid_classification", "classification_submodel"))
+
+
+def _submodel_of(layer):
+    for prefix, sub in _SUBMODELS:
+        if layer == prefix or (layer.startswith(prefix + "_") and layer[len(prefix) + 1:].isdigit()):
+            return sub
+    return None
+
+
 def save_keras_weights(path, state, keras_version="2.2.4", backend="tensorflow"):
-    """Write {'<layer>/<param>': array} as a Keras save_weights() file: '/<layer>/<layer>/<param>:0' float32 datasets, the
-    'weight_names' attribute on every layer group and 'layer_names' / 'backend' / 'keras_version' on the root."""
+    """Write {'<layer>/<param>': array} the way Keras' save_weights() lays the reference's model out: float32 datasets
+    '/<layer>/<layer>/<param>:0' with 'weight_names' = ['<layer>/<param>:0', ...] on every layer group, EXCEPT the head convs,
+    which live in the nested models of model/defineModel.py:78-167 and are therefore stored under ONE group per submodel:
+    '/regression_submodel/pyramid_regression_0/kernel:0' ... with 'weight_names' = ['pyramid_regression_0/kernel:0', ...] and
+    'regression_submodel' / 'classification_submodel' listed in the root's 'layer_names' (this is what
+    load_weights(by_name=True) of RetinaNet.py:70-79 matches on).  Root attributes: 'layer_names', 'backend', 'keras_version'.
+    Weights only: no 'model_config' (a model.save() file) is produced."""
     layers = {}
     for key, arr in state.items():
         layer, param = key.rsplit("/", 1)
         layers.setdefault(layer, {})[param] = np.asarray(arr, np.float32)
     w = _Writer()
-    tops = {}
-    order = list(layers)
-    for layer in order:
-        params = sorted(layers[layer], key=lambda q: _PARAM_ORDER.index(q) if q in _PARAM_ORDER else len(_PARAM_ORDER))
-        inner = w.group({p + ":0": w.dataset(layers[layer][p]) for p in params})[0]
-        tops[layer] = w.group({layer: inner}, {"weight_names": ["%s/%s:0" % (layer, p) for p in params]})[0]
+    tops, order, nested = {}, [], {}
+
+    def ordered(layer):
+        return sorted(layers[layer], key=lambda q: _PARAM_ORDER.index(q) if q in _PARAM_ORDER else len(_PARAM_ORDER))
+
+    for layer in layers:
+        sub = _submodel_of(layer)
+        if sub is None:
+            params = ordered(layer)
+            inner = w.group({p + ":0": w.dataset(layers[layer][p]) for p in params})[0]
+            tops[layer] = w.group({layer: inner}, {"weight_names": ["%s/%s:0" % (layer, p) for p in params]})[0]
+            order.append(layer)
+        else:
+            if sub not in nested:
+                nested[sub] = []
+                order.append(sub)                                   # the submodel sits where its first conv appears
+            nested[sub].append(layer)
+    for sub, members in nested.items():
+        kids, names = {}, []
+        for layer in members:
+            params = ordered(layer)
+            kids[layer] = w.group({p + ":0": w.dataset(layers[layer][p]) for p in params})[0]
+            names += ["%s/%s:0" % (layer, p) for p in params]
+        tops[sub] = w.group(kids, {"weight_names": names})[0]
     root = w.group(tops, {"layer_names": order, "backend": backend, "keras_version": keras_version})
     with open(path, "wb") as f:
         f.write(w.finish(root))

@@ -121,6 +121,8 @@ class Model:
         hist = History()
         callbacks = callbacks or []
         steps = steps_per_epoch or len(generator)
+        if self._compiled is None:                                # fit without compile(): the defaults _get_trainer would take
+            self._compiled = Adam(lr=1e-4, clipnorm=0.001)
         for cb in callbacks:
             if hasattr(cb, "set_model"):
                 cb.set_model(self)

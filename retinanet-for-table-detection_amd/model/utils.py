@@ -24,6 +24,38 @@ def preprocess_image(x, mode='tf'):
     return _rt.host(out)
 
 
+def shift(shape, stride, anchors):
+    """ model/utils.py:51-80 (the in-graph float32 twin of anchors.shift): anchors shifted over a (rows, cols) map,
+    centres (i + 0.5) * stride, order y -> x -> anchor -> (shape[0] * shape[1] * A, 4) float32 (rtn_anchors_f32)."""
+    import ctypes as C
+    from . import anchors as _anchors
+    base = np.asarray(anchors, np.float32)
+    h = _rt.handle()
+    cfg, n = _anchors._cfg([shape], [stride], [base.astype(np.float64)])
+    out = torch.empty(n, 4, dtype=torch.float32, device="cuda")
+    h.check(L.lib.rtn_anchors_f32(h.raw, C.byref(cfg), out.data_ptr()))
+    return _rt.host(out)
+
+
+def bbox_transform_inv(boxes, deltas, mean=None, std=None):
+    """ model/utils.py:84-112: boxes (B, N, 4) + deltas * std + mean applied to the box width / height (rtn_regress_boxes,
+    the kernel behind layers.RegressBoxes)."""
+    import ctypes as C
+    if mean is None:
+        mean = [0, 0, 0, 0]
+    if std is None:
+        std = [0.2, 0.2, 0.2, 0.2]
+    h = _rt.handle()
+    a, r = _rt.dev(np.asarray(boxes), torch.float32), _rt.dev(np.asarray(deltas), torch.float32)
+    if a.shape != r.shape or a.shape[-1] != 4:
+        raise ValueError("boxes and deltas must both be (B, N, 4), got %s and %s" % (tuple(a.shape), tuple(r.shape)))
+    out = torch.empty_like(a)
+    m4 = (C.c_float * 4)(*[float(v) for v in mean])
+    s4 = (C.c_float * 4)(*[float(v) for v in std])
+    h.check(L.lib.rtn_regress_boxes(h.raw, a.data_ptr(), r.data_ptr(), a.numel() // 4, m4, s4, out.data_ptr()))
+    return _rt.host(out)
+
+
 def compute_resize_scale(image_shape, min_side=800, max_side=1333):
     """ model/utils.py:116-137."""
     (rows, cols, _) = image_shape

@@ -38,17 +38,29 @@ class Trainer:
         self.lr, self.clipnorm, self.b1, self.b2, self.eps = lr, clipnorm, beta1, beta2, eps
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
         self.pg = process_group
+        self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on side HIP streams
+        self.wgrad_lanes = max(1, min(self.WG_LANES, int(os.environ.get("RTN_WGRAD_LANES", "3"))))
+        self._wg_stream = None
+        self._bind_engine_state()
+
+    def _bind_engine_state(self):
+        """Everything derived from the engine's loaded state: the f32 master copy, fold / gradient scales, Adam moments, dgrad
+        weights, the backward plans (which hold descriptors into the forward plan's activation buffers) and the gradient
+        bucketer.  Engine.load_state() reallocates the flat weights and drops its plans, so a Trainer that lived through it
+        starts over from the newly loaded weights with fresh optimizer state - exactly what a new Trainer would hold."""
+        self._epoch = self.eng.load_epoch
         self.step_count = 0
         self.bplans = {}
         self._init_params()
         self.bucketer = None
-        self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on side HIP streams
-        self.wgrad_lanes = max(1, min(self.WG_LANES, int(os.environ.get("RTN_WGRAD_LANES", "3"))))
-        self._wg_stream = None
         if self.pg is not None:
             segs = [(name, lo["woff"], lo["woff"] + lo["rows"] * lo["K"]) for name, lo in self.eng.layout.items()]
             segs.append(("__biases__", self.NW, self.NW + self.NB))           # FPN/head biases: one last segment
             self.bucketer = Par.GradBucketer(self.grad, segs, group=self.pg)
+
+    def _check_engine_state(self):
+        if self._epoch != self.eng.load_epoch:
+            self._bind_engine_state()
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self):
@@ -316,6 +328,7 @@ class Trainer:
                         raise RuntimeError("grouped dgrad of %s needs uniform epilogue flags" % name)
                     dd.g[gi] = g
                 dd.flags = flags_all
+                L.attach_conv_workspace(eng.h, dd)                   # caller-owned K-split slabs, one buffer per launch
                 bops.append(("dgrad", dd, name))
             elif kind == "pool":
                 x, y = op[1], op[2]
@@ -325,7 +338,8 @@ class Trainer:
                 gstate[tid(x)] = "buf"
         ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
-        bp = {"bops": bops, "keep": keep, "ws": ws, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
+        bias_bops = [i for i, b in enumerate(bops) if b[0] == "wgrad" and b[4] is not None]
+        bp = {"bops": bops, "keep": keep, "ws": ws, "last_bias_bop": bias_bops[-1] if bias_bops else -1, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
               "d_reg": d_reg, "d_cls": d_cls, "dyp_cls": dyp_cls, "loss_ws": loss_ws, "plan": plan, "rowinfo": {}}
         self.bplans[key] = bp
         return bp
@@ -416,6 +430,7 @@ class Trainer:
     def forward_backward(self, images, regression_batch, labels_batch):
         """Forward, loss and backward; leaves dL/dparams in self.grad (flat f32) and returns the device tensor
         loss_sums = [sum focal terms, sum smooth-L1 terms, #positives (labels), #positives (regression)] of THIS rank."""
+        self._check_engine_state()
         eng, lib = self.eng, L.lib
         h = eng.h
         B, H, W, _ = images.shape
@@ -482,11 +497,13 @@ class Trainer:
                 h.check(lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr() if b[4] is not None else None,
                                                       b[5] if b[4] is not None else 0, tab.data_ptr(), tab.numel()))
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
-                    if on_side:
-                        with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream
-                            self.bucketer.layer_done(b[3])
-                    else:
-                        self.bucketer.layer_done(b[3])
+                    done_names = [b[3]] + (["__biases__"] if bi == bp["last_bias_bop"] else [])   # last fused bias gradient
+                    for dn in done_names:
+                        if on_side:
+                            with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream
+                                self.bucketer.layer_done(dn)
+                        else:
+                            self.bucketer.layer_done(dn)
             elif kind == "dgrad":
                 h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
             elif kind == "bgrad":
@@ -517,6 +534,9 @@ class Trainer:
 
     def optimizer_step(self, lr=None):
         """Global-norm clip + Adam on the flat parameter vector, re-emission of the forward and dgrad weights."""
+        if self._epoch != self.eng.load_epoch:
+            raise RuntimeError("Engine.load_state() ran between forward_backward() and optimizer_step(): the gradient belongs to "
+                               "the previous weights")
         eng, lib, h = self.eng, L.lib, self.eng.h
         eng._bind_stream()
         if self.bucketer is not None:                # sum of per-rank gradients == gradient of the merged batch

@@ -30,16 +30,18 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layout_matches_header(pkg, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtn.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(rtn_conv_group_t),sizeof(rtn_conv_desc_t),sizeof(rtn_anchor_cfg_t),'
                    'offsetof(rtn_conv_desc_t,w),offsetof(rtn_conv_desc_t,flags),offsetof(rtn_anchor_cfg_t,base),'
-                   'sizeof(rtn_conv_src2_t),offsetof(rtn_conv_src2_t,step));return 0;}\n')
+                   'sizeof(rtn_conv_src2_t),offsetof(rtn_conv_src2_t,step),'
+                   'offsetof(rtn_conv_desc_t,workspace),offsetof(rtn_conv_desc_t,workspace_bytes));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     L = pkg._lib
     want = [C.sizeof(L.ConvGroup), C.sizeof(L.ConvDesc), C.sizeof(L.AnchorCfg), L.ConvDesc.w.offset, L.ConvDesc.flags.offset,
-            L.AnchorCfg.base.offset, C.sizeof(L.ConvSrc2), L.ConvSrc2.step.offset]
+            L.AnchorCfg.base.offset, C.sizeof(L.ConvSrc2), L.ConvSrc2.step.offset,
+            L.ConvDesc.workspace.offset, L.ConvDesc.workspace_bytes.offset]
     assert got == want
 
 

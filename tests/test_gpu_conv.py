@@ -126,6 +126,7 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
         keep.append(xd)
         wants.append(want)
     d.flags = flags
+    L.attach_conv_workspace(handle, d)            # the split-K / tail-split paths take their slabs from the caller
     handle.check(L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
     gots = []

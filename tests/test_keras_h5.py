@@ -40,7 +40,15 @@ def test_writer_reader_round_trip(tmp_path, backbone):
     assert "/conv1/conv1/kernel:0" in raw and "/bn_conv1/bn_conv1/moving_variance:0" in raw and "/P3/P3/bias:0" in raw
     attrs = K.read_attributes(path)
     layers = list(attrs["/"]["layer_names"])
-    assert layers[0] == "conv1" and len(layers) == len(set(k.split("/")[0] for k in st))      # > 64: several symbol-table leaves
+    # the ten head convs sit in the two nested submodels (model/defineModel.py:78-167), every other layer is a top-level group
+    n_head = len(set(k.split("/")[0] for k in st if k.startswith(("pyramid_regression", "pyramid_classification"))))
+    assert layers[0] == "conv1" and len(layers) == len(set(k.split("/")[0] for k in st)) - n_head + 2    # > 64: several leaves
+    assert "regression_submodel" in layers and "classification_submodel" in layers and "pyramid_regression_0" not in layers
+    assert "/regression_submodel/pyramid_regression_0/kernel:0" in raw and "/classification_submodel/pyramid_classification/bias:0" in raw
+    assert not any(p.startswith("/pyramid_") for p in raw)
+    wn = list(attrs["/regression_submodel"]["weight_names"])
+    assert wn[:2] == ["pyramid_regression_0/kernel:0", "pyramid_regression_0/bias:0"] and len(wn) == 10
+    assert wn[-2:] == ["pyramid_regression/kernel:0", "pyramid_regression/bias:0"]
     assert attrs["/"]["backend"] == "tensorflow"
     assert list(attrs["/bn_conv1"]["weight_names"]) == ["bn_conv1/gamma:0", "bn_conv1/beta:0", "bn_conv1/moving_mean:0", "bn_conv1/moving_variance:0"]
     assert list(attrs["/P5"]["weight_names"]) == ["P5/kernel:0", "P5/bias:0"]
@@ -74,7 +82,7 @@ def _link(name, addr):
     return struct.pack("<BBB", 1, 0, len(n)) + n + struct.pack("<Q", addr)
 
 
-def hand_made_file():
+def hand_made_file(nested=False):
     buf = bytearray(100)                                       # version-1 superblock: 100 bytes with the root entry
 
     def alloc(b):
@@ -123,7 +131,11 @@ def hand_made_file():
     # groups stored as Link messages (compact new-style groups): /layer/{kernel:0,bias:0}, root {layer, extra}
     linfo = struct.pack("<BB", 0, 0) + struct.pack("<QQ", K.UNDEF, K.UNDEF)
     layer = header([_msg(2, linfo), _msg(6, _link("kernel:0", chunked)), _msg(6, _link("bias:0", contig))])
-    root = header([_msg(2, linfo), _msg(6, _link("layer", layer)), _msg(6, _link("extra", compact))])
+    if nested:     # Keras' layout of a nested model: /regression_submodel/pyramid_regression_0/{kernel:0,bias:0}
+        sub = header([_msg(2, linfo), _msg(6, _link("pyramid_regression_0", layer))])
+        root = header([_msg(2, linfo), _msg(6, _link("regression_submodel", sub)), _msg(6, _link("extra", compact))])
+    else:
+        root = header([_msg(2, linfo), _msg(6, _link("layer", layer)), _msg(6, _link("extra", compact))])
     sb = K.SIGNATURE + struct.pack("<BBBBBBBBHHI", 1, 0, 0, 0, 0, 8, 8, 0, 4, 16, 0) + struct.pack("<HH", 32, 0)
     sb += struct.pack("<QQQQ", 0, K.UNDEF, len(buf), K.UNDEF) + struct.pack("<QQII16x", 0, root, 0, 0)
     assert len(sb) == 100
@@ -147,6 +159,19 @@ def test_reader_on_hand_assembled_structures(tmp_path):
     shifted.write_bytes(b"\0" * 512 + bytes(moved))
     ds2 = K.read_datasets(str(shifted))
     assert set(ds2) == set(ds) and all(np.array_equal(ds2[k], ds[k]) for k in ds)
+
+
+def test_reader_on_a_hand_assembled_nested_submodel_file(tmp_path):
+    """The head convs of a real Keras file sit one group deeper, inside 'regression_submodel' / 'classification_submodel'
+    (model/defineModel.py:78-167): the state keys still come out as '<inner layer>/<param>'."""
+    data, a, v, w = hand_made_file(nested=True)
+    path = tmp_path / "nested.h5"
+    path.write_bytes(data)
+    ds = K.read_datasets(str(path))
+    assert set(ds) == {"/regression_submodel/pyramid_regression_0/kernel:0", "/regression_submodel/pyramid_regression_0/bias:0", "/extra"}
+    st = K.load_keras_state(str(path))
+    assert set(st) == {"pyramid_regression_0/kernel", "pyramid_regression_0/bias"}
+    assert np.array_equal(st["pyramid_regression_0/kernel"], a) and np.array_equal(st["pyramid_regression_0/bias"], w)
 
 
 def test_reader_refuses_what_it_does_not_implement(tmp_path):
