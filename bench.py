@@ -11,10 +11,17 @@ architecture (no checkpoint exists in the reference); the classification bias is
 per image pass the 0.05 score threshold, the load a trained detector puts on the NMS stage.
 
 The JSON line also carries
-  roofline     — the dominant kernel (conv_igemm_kernel, bf16 MFMA): algorithmic FLOPs of all its launches in a step
-                 / their summed duration measured with events on the launch stream; per-launch averages alongside.
+  roofline     — bound "mfma": `achieved` = algorithmic conv FLOPs of a step / the TIMED region's time per step (the number the
+                 driver's clock anchors; stream lanes overlap launches there), `frac` against the 2.5 PF dense bf16 peak;
+                 `dominant` = the kernel with the largest share of GPU time (the head-tower layers), with its own FLOPs per
+                 launch and its launch duration measured live with events on its launch stream, launches one after another
+                 (`serial_*` fields: the same serial measurement summed over all conv launches — it exceeds ms_per_step
+                 because the timed region overlaps lanes); `traffic` = HBM bytes per step from the committed PMC passes, only
+                 when that file was collected on the same launch plan (else null, with the reason).
   cpu_baseline — the oracle (oracle/ref_net.py + ref_numpy.py: torch-CPU fp32 restatement, kind "port") timed on this
                  host's cores on a bounded sample (whole path for 1 image of the same canvas).
+  secondary    — BASELINE.json configs[2]/[3]: the batch-16-per-GPU TRAINING step (targets + forward + focal/smooth-L1 +
+                 backward + bucketed gradient all-reduce under DP + clipnorm Adam), same timing protocol, 20 steps.
 """
 import argparse
 import importlib
@@ -35,6 +42,7 @@ GFLOP_PER_IMAGE = 416.1            # 208.06 GMAC forward, ever
 BF16_DENSE_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 CAND_FRACTION = 0.01               # share of anchors above the 0.05 score threshold (set by calibration)
 CLS_BIAS = -5.27                   # default used by tools/ when no calibration runs
+TOWER_KERNEL = "conv_igemm3_kernel<2, 256>"   # symbol of the kernel the launcher picks for the head-tower layers (rtn_conv.hip)
 
 
 def synth_images(torch, B, seed, device):
@@ -70,15 +78,28 @@ def conv_bytes(op_desc, batch):
     return float(total)
 
 
-def pmc_traffic():
-    """HBM bytes per conv launch from the committed PMC passes (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
-    rocprofv3 --pmc in separate passes, collected on this same bench command); None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+def pmc_traffic(n_conv_launches):
+    """HBM bytes per step of the conv launches from the newest committed PMC summary (profiles/*pmc_traffic*.json: FETCH_SIZE x2
+    + WRITE_SIZE, rocprofv3 --pmc in separate passes on this same bench command, see tools/pmc_traffic.py).  The counters are
+    NOT collected in this run: the file is only quoted when it was collected on the same launch plan (conv launches per step),
+    and the line says which file and commit.  Returns (bytes_per_step or None, note)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), key=os.path.getmtime)
+    if not files:
+        return None, "no PMC summary committed"
+    path = files[-1]
     try:
         with open(path) as f:
-            return json.load(f)["conv_total"]
-    except (OSError, KeyError, ValueError):
-        return None
+            j = json.load(f)
+        tot = j["conv_total"]
+        launches = j.get("bench_launches_per_step")
+    except (OSError, KeyError, ValueError) as e:
+        return None, "unreadable PMC summary %s: %s" % (os.path.basename(path), e)
+    tag = "profiles/%s (commit %s, plan of %s conv launches/step, 2 x FETCH_SIZE + WRITE_SIZE)" % (
+        os.path.basename(path), j.get("git_commit", "unrecorded"), launches)
+    if launches is None or int(launches) != int(n_conv_launches):
+        return None, "stale: %s, this plan has %d" % (tag, n_conv_launches)
+    return float(tot["hbm_bytes_per_step"]), tag
 
 
 def cpu_baseline(torch, state, threads):
@@ -108,9 +129,11 @@ TRAIN_BATCH = 16                   # BASELINE.json configs[2]: batch 16 per GPU
 TRAIN_GFLOP_PER_IMAGE = 1248.4     # ~3x forward (dgrad + wgrad for every conv)
 
 
-def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
+def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, device):
     """One step = forward + focal/smooth-L1 + backward + (bucketed RCCL all-reduce under DP) + clipnorm Adam on a batch of
-    16 synthetic pages per GPU; anchor targets are produced on the device by rtn_anchor_targets inside the timed region."""
+    16 synthetic pages per GPU; anchor targets are produced on the device by rtn_anchor_targets inside the timed region.
+    Same protocol as the inference line: `warmup` untimed steps, exactly `steps` timed steps between barrier + synchronize,
+    max over ranks.  Returns the result object on rank 0 (None elsewhere)."""
     import ctypes as C
     import numpy as np
     T = importlib.import_module(PKG + ".trainer")
@@ -147,11 +170,11 @@ def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -159,21 +182,28 @@ def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank != 0:
+        return None
+    value = world * B * steps / elapsed
+    s = tr.norm_sums.cpu().numpy()
+    achieved = value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world
+    return {"metric": "images/sec RetinaNet R50-FPN 800x1333 training step", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ResNet50-FPN RetinaNet training step 800x1333 bf16 batch 16/GPU: targets + fwd + "
+                                   "focal/smooth-L1 + bwd + clipnorm Adam (BASELINE.json configs[2]/[3])",
+                       "batch_per_gpu": B, "positives_merged_batch": float(s[2]),
+                       "parallelism": "dp%d (bucketed gradient all-reduce overlapped with backward)" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv fwd+dgrad+wgrad (whole step)", "achieved": achieved,
+                         "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
+                         "flop_per_step": TRAIN_GFLOP_PER_IMAGE * 1e9 * B, "traffic": None}}
+
+
+def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
+    out = measure_train(args.steps, args.warmup, torch, dist, E, Wt, rank, local_rank, world, device)
     if rank == 0:
-        value = world * B * args.steps / elapsed
-        s = tr.norm_sums.cpu().numpy()
-        achieved = value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world
-        print(json.dumps({"metric": "images/sec RetinaNet R50-FPN 800x1333 training step", "value": value, "unit": "images/sec",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": "ResNet50-FPN RetinaNet training step 800x1333 bf16 batch 16/GPU: targets + fwd + "
-                                                 "focal/smooth-L1 + bwd + clipnorm Adam (BASELINE.json configs[2]/[3])",
-                                     "batch_per_gpu": B, "positives_merged_batch": float(s[2]),
-                                     "parallelism": "dp%d (bucketed gradient all-reduce overlapped with backward)" % world},
-                          "roofline": {"bound": "mfma", "kernel": "conv fwd+dgrad+wgrad (whole step)", "achieved": achieved,
-                                       "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                                       "traffic": None},
-                          "cpu_baseline": None}))
+        out["cpu_baseline"] = None
+        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -185,6 +215,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the training-step measurement (the `secondary` object)")
+    ap.add_argument("--secondary-steps", type=int, default=20)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, BASELINE.json configs[1]) or train (configs[2]/[3]: batch 16/GPU training step)")
     args = ap.parse_args()
@@ -250,20 +282,35 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: events around every conv launch of extra (untimed) steps
+        # ---- roofline.  `achieved` comes from the TIMED region (algorithmic conv FLOPs of a step / ms_per_step).  Beside it:
+        # events around every launch of extra (untimed) steps, all launches on ONE stream one after another - the serial sum and
+        # the solo duration of the dominant kernel (the head-tower layers: the largest share of GPU time).
         plan = eng._plan(BATCH, CANVAS[0], CANVAS[1])
         active = eng.active_ops(plan)
         conv_ops = [op for op in active if op[0] in ("conv", "dual")]
         fused_stem = any(op[0] == "stem" for op in active)          # conv1 + ReLU + pool1 in one kernel: its MFMA work is conv1's
         stem_conv = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "conv1"][0]
         # a "dual" launch is branch2c with the projection shortcut appended along K: the same FLOPs as the two layers it replaces
-        flops_step = sum(conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
-                         for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
+        def op_flops(op):
+            return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
+        flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
+        ms_per_step = 1e3 * elapsed / args.steps
+        achieved = flops_step / (ms_per_step * 1e-3) / 1e12
         reps = 3
         per_op_ms = eng.profile_ops(x, reps=reps)
-        conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem", "dual")) / reps
-        other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem", "dual")) / reps
-        achieved = flops_step / (conv_ms * 1e-3) / 1e12
+        serial_conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem", "dual")) / reps
+        serial_other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem", "dual")) / reps
+        tower = [(op, ms / reps) for op, (kind, ms) in zip(active, per_op_ms[:len(active)])
+                 if op[0] == "conv" and op[2].startswith(("pyramid_regression_", "pyramid_classification_"))]
+        dom = None
+        if tower:
+            t_ms = sum(ms for _, ms in tower) / len(tower)
+            t_fl = sum(op_flops(op) for op, _ in tower) / len(tower)
+            dom = {"kernel": "%s (head-tower layers: 3x3 256->256 + ReLU over P3..P7, one grouped launch each)" % TOWER_KERNEL,
+                   "launches_per_step": len(tower), "flop_per_launch": t_fl, "avg_launch_ms_solo": t_ms,
+                   "achieved_solo": t_fl / (t_ms * 1e-3) / 1e12, "frac_solo": t_fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                   "share_of_serial_conv_time": len(tower) * t_ms / serial_conv_ms,
+                   "how": "events on the launch stream around each launch, launches one after another, %d passes" % reps}
         ncand = int((plan["classification"] > 0.05).sum().item())
         bytes_step = sum(conv_bytes(op[1], BATCH) + ((BATCH * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
                          for op in conv_ops)
@@ -271,18 +318,21 @@ def main():
         if fused_stem:                                                 # image in (bf16, 3 ch), pooled tensor out, filters
             H1, W1 = (CANVAS[0] - 1) // 2 + 1, (CANVAS[1] - 1) // 2 + 1
             bytes_step += BATCH * (CANVAS[0] * CANVAS[1] * 3 * 2 + ((H1 + 1) // 2) * ((W1 + 1) // 2) * 64 * 2) + 64 * 256 * 2
-        pmc = pmc_traffic()
-        roofline = {"bound": "mfma", "kernel": "conv_igemm2_kernel/conv_igemm_kernel<bf16> (all conv launches of a step)",
+        traffic, traffic_note = pmc_traffic(n_launch)
+        roofline = {"bound": "mfma", "kernel": "all conv launches of a step (implicit-GEMM MFMA kernels, bf16)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                    "traffic": (pmc["hbm_bytes_per_launch"] if pmc else None),
-                    "traffic_source": ("profiles/r1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, bytes per launch)" if pmc else None),
-                    "algorithmic_bytes_per_launch": bytes_step / n_launch,
-                    "launches_per_step": n_launch, "avg_launch_ms": conv_ms / n_launch,
-                    "flop_per_step": flops_step, "flop_per_launch": flops_step / n_launch,
-                    "conv_ms_per_step": conv_ms, "non_conv_ms_per_step": other_ms}
+                    "achieved_from": "flop_per_step / ms_per_step of the timed region",
+                    "flop_per_step": flops_step, "launches_per_step": n_launch,
+                    "traffic": traffic, "traffic_per": "step", "traffic_source": traffic_note,
+                    "algorithmic_bytes_per_step": bytes_step,
+                    "hbm_floor_ms_at_6.3TBps": bytes_step / 6.3e12 * 1e3,
+                    "dominant": dom,
+                    "serial_conv_ms_per_step": serial_conv_ms, "serial_non_conv_ms_per_step": serial_other_ms,
+                    "serial_note": "per-launch event sums with every launch on one stream; larger than ms_per_step because the "
+                                   "timed region runs the graph's forks on side streams"}
         out = {"metric": "images/sec RetinaNet R50-FPN 800x1333 inference", "value": value, "unit": "images/sec",
-               "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "ResNet50-FPN RetinaNet inference 800x1333 bf16 batch 8/GPU incl. decode+NMS "
                                       "(BASELINE.json configs[1])",
@@ -295,6 +345,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(torch, state, threads)
         else:
             out["cpu_baseline"] = None
+    # ---- secondary: the training step (BASELINE.json configs[2]; configs[3] when the driver launches N ranks), every rank takes part
+    if not args.no_secondary:
+        del eng
+        torch.cuda.empty_cache()
+        try:
+            sec = measure_train(args.secondary_steps, min(args.warmup, 3), torch, dist, E, Wt, rank, local_rank, world, device)
+        except Exception as e:          # the inference line must survive a failure here; the failure is reported, not hidden
+            sec = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

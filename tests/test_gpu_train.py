@@ -132,3 +132,38 @@ def test_loss_decreases_over_steps(pkg):
     losses = [tr.train_on_batch(xd, regd, labd)[0] for _ in range(10)]
     print("losses:", ["%.4f" % v for v in losses])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_trainer_follows_engine_load_state(pkg):
+    """Engine.load_state() reallocates the flat weights and drops the forward plans.  A Trainer that lived through it must not
+    write its old master copy over the new weights nor differentiate through the discarded plan's activation buffers: its next
+    step equals the step of a Trainer created after the load (fp32: bit-identical losses, gradients within the float-atomic
+    noise of the weight gradient, 1e-5 of the gradient scale)."""
+    E, Wt, T = mods(pkg)
+    st_a = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    st_b = Wt.init_state("resnet50", 1, 9, seed=9, randomize_bn=True, cls_bias=-2.0, tame=True)
+    x, reg_t, lab_t = make_batch(2, seed=21)
+    xd, regd, labd = torch.as_tensor(x).cuda(), torch.as_tensor(reg_t).cuda(), torch.as_tensor(lab_t).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype="f32")
+    eng.load_state(st_a)
+    tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001)
+    tr.train_on_batch(xd, regd, labd)
+    eng.load_state(st_b)                                   # e.g. a checkpoint resume into a live model
+    loss_live = tr.train_on_batch(xd, regd, labd)
+    torch.cuda.synchronize()
+    assert tr.step_count == 1                              # fresh optimizer state for the loaded weights
+    g_live, w_live = tr.grad.clone(), tr.master.clone()
+    eng2 = E.Engine("resnet50", 1, 9, dtype="f32")
+    eng2.load_state(st_b)
+    tr2 = T.Trainer(eng2, lr=1e-4, clipnorm=0.001)
+    loss_new = tr2.train_on_batch(xd, regd, labd)
+    torch.cuda.synchronize()
+    assert loss_live == loss_new, (loss_live, loss_new)
+    scale = float(tr2.grad.abs().max())
+    assert scale > 0 and float((g_live - tr2.grad).abs().max()) <= 1e-5 * scale
+    assert float((w_live - tr2.master).abs().max()) <= 1e-3 * 1e-4
+    # and a load between backward and the optimizer step is refused: that gradient belongs to other weights
+    tr.forward_backward(xd, regd, labd)
+    eng.load_state(st_a)
+    with pytest.raises(RuntimeError):
+        tr.optimizer_step()
