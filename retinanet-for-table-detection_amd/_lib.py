@@ -87,6 +87,7 @@ SIGNATURES = {
     "rtn_last_error": (C.c_char_p, [_P]),
     "rtn_version": (C.c_char_p, []),
     "rtn_conv2d_workspace_bytes": (_SZ, [_P, C.POINTER(ConvDesc)]),
+    "rtn_debug_last_conv_impl": (_I, [_P]),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),

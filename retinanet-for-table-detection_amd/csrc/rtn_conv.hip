@@ -1284,7 +1284,7 @@ int rtn_env_int(const char* name, int dflt) {
 }
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
-    return (v >= 1 && v <= 3) ? v : 0;
+    return (v >= 1 && v <= 4) ? v : 0;                 // 4 = the persistent 8-phase kernel of rtn_conv_halo8.hip where it applies
 }
 
 int ilog2_exact(int v) {
@@ -1418,6 +1418,20 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     // kernel wherever it applies, 0 disables it.
     const int halo_env = rtn_env_int("RTN_CONV_HALO", 1);
     if (impl == 2 && halo_ok && rtn_conv_impl_override() == 0 && (halo_env == 2 || (halo_env == 1 && d->N >= 256 && bn2 == 256))) impl = 3;
+    // Fourth generation (rtn_conv_halo8.hip): the layers generation 3 runs on 256-wide tiles (the grouped head towers, P3),
+    // persistent and on the staggered 8-phase schedule.  RTN_CONV_H8=0 keeps generation 3, 2 takes every layer the kernel accepts
+    // (as RTN_CONV_IMPL=4 does); RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers),
+    // RTN_CONV_H8_STAGGER=0 runs the two wave groups in lockstep (A/B).
+    if (!query && !s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16) {
+        const int h8 = rtn_env_int("RTN_CONV_H8", 1);
+        const int forced = rtn_conv_impl_override();
+        if ((forced == 4 || (forced == 0 && (h8 == 2 || (h8 == 1 && impl == 3 && bn2 == 256))))) {
+            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0);
+            if (rc == RTN_OK) h->last_conv_impl = 4;
+            if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
+        }
+    }
+    if (impl == 4) impl = halo_ok ? 3 : 2;
     const int TM = impl == 3 ? BM2 - (d->KW - 1) : (impl == 2 ? BM2 : BM);
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
@@ -1714,8 +1728,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         }
     }
     RTN_CHECK_LAUNCH(h, "conv_igemm_kernel");
+    h->last_conv_impl = impl;
     return RTN_OK;
 }
+
+extern "C" int rtn_debug_last_conv_impl(rtn_handle_t h) { return h ? h->last_conv_impl : RTN_EINVAL; }
 
 extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) { return conv_launch(h, d); }
 

@@ -1,0 +1,419 @@
+// rtn_conv_halo8.hip — the head-tower convolution kernel: stride-1 'same' KHxKW convolution with <= 256 output channels as a
+// PERSISTENT 256 x 256 implicit GEMM on the staggered 8-phase schedule (cdna_hip_programming.md §5, "The 256^2 8-phase template").
+//
+// Replaces, for the layers it accepts, the third kernel generation of rtn_conv.hip (conv_igemm3_kernel<2, 256>) on
+//   model/defineModel.py:101-117,155-163  the 4 x [3x3 conv 256 + ReLU] towers of both heads over P3..P7 (one grouped launch),
+//   model/defineModel.py:183-203           P3 / P4 / P5 (3x3, 256 -> 256), keras_resnet's res4 branch2b (3x3, 256 -> 256).
+//
+// What is different from generation 3 (same halo idea: the KW taps of a kernel row read ONE staged image of 256 consecutive
+// input pixels, shifted by one row of the image per tap):
+//   * K step (64 deep) = 4 phases of {fragment reads + LDS-DMA issue | s_barrier | 16 MFMAs | s_barrier}.  Waves 4-7 run one
+//     barrier behind waves 0-3 (SIMD partners are (w, w+4)), so one wave of every SIMD multiplies while the other reads.
+//   * LDS-DMA stays in flight across barriers: B tiles in a ring of 3 (the B tile of step s+2 is issued during step s),
+//     halos double-buffered one (kh, chunk) group ahead, ONE counted s_waitcnt vmcnt(N) per K step (phase 4), never 0.
+//     A staged buffer is read one phase after the wait that retires it and restaged >= 2 phases after its last read.
+//   * persistent: a workgroup walks its tiles as ONE stream of K steps; the first stages of the next tile are issued during the
+//     last steps of the current one, so no prologue latency and no launch gap sits between tiles, and the epilogue's stores
+//     drain while the next tile multiplies.
+//   * no LDS in the epilogue: the B tile is staged with its weight rows PERMUTED (LDS position 16 j + c holds output channel
+//     8 c + j), so that lane (q, c) of a wave ends up with 8 CONSECUTIVE channels of a pixel in its 8 column fragments and stores
+//     16 bytes per row straight from registers (one wave-instruction = 4 pixel rows x 256 contiguous bytes).  Bias is the
+//     accumulators' initial value.
+//   * horizontal image edge: instead of zeroing A fragments in registers (16 v_cndmask per step), row 255 of every halo is a
+//     ZERO row (TM = 256 - KW output rows per tile) and a lane whose tap leaves the image reads that row.
+//
+// LDS (160 KiB, all of it): B ring 3 x 32 KiB at 0, halos 2 x 32 KiB at 96 KiB.  One workgroup (512 threads) per CU.
+#include "rtn_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr unsigned OOB = 0xFFFFFF00u;                 // beyond every descriptor: loads return zeros, stores are dropped
+constexpr int H8_THREADS = 512;
+constexpr int H8_LDS = 160 * 1024;
+constexpr unsigned B_STAGE = 32768, A_BASE = 3 * 32768, A_TOGGLE = 0x18000u ^ 0x20000u;
+constexpr unsigned ZERO_ROW = 255u * 128u;
+
+struct H8Group {
+    const char* in;
+    char* out;
+    unsigned in_bytes, out_bytes;
+    int Hin, Win, M, tile_begin;
+    int in_row_stride_b;
+    float inv_cells, inv_w;
+};
+
+struct H8Params {
+    H8Group g[RTN_MAX_GROUPS];
+    const char* w;
+    const float* bias;
+    unsigned w_bytes;
+    int ngroups, ntiles;
+    int N, Kbytes, KH, nchunk, pad_t, pad_l, relu, out_ld, pix_b;
+};
+
+__device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+// 64 lanes x 16 B from (descriptor, per-lane byte offset `voff` + uniform `soff`) to LDS bytes [lds_addr, lds_addr + 1024).
+// asm so that hipcc neither counts nor drains it; the kernel's own counted waits cover it.
+__device__ __forceinline__ void dma16(const i32x4& srd, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(soff)
+                 : "memory");
+}
+
+// f / d for 0 <= f < 2^24 with inv = 1.0f / d: the float product is within one of the quotient
+__device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r) {
+    q = (int)((float)f * inv);
+    r = f - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int KW, bool STAGGER>
+__global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
+    constexpr int TM = 256 - KW;                       // output rows per tile; halo rows 0 .. 254, row 255 = zeros
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2;                         // SIMD partners (w, w + 4) sit in different groups
+    const int wm = wave >> 1, wn = wave & 1;           // wave tile: rows [64 wm, +64) x columns [128 wn, +128)
+    const int lr = lane >> 3, sc = (lane & 7) ^ lr;    // staging: row inside an 8-row piece, SOURCE chunk (swizzle on the source)
+    const int lrow = lane & 15, kq = lane >> 4;        // fragment row / k quarter of this lane
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int G = p.KH * p.nchunk;                     // (kh, chunk) groups per tile
+    const int nchunk = p.nchunk;
+    const i32x4 w_srd = make_srd(p.w, p.w_bytes);
+
+    // ---- B staging: piece d of this wave fills LDS positions P = 64 d + 8 wave + lr; position 128 wn' + 16 j + c holds weight
+    // row 128 wn' + 8 c + j (the column permutation that makes the epilogue's stores contiguous)
+    unsigned wrow_off[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int P = d * 64 + wave * 8 + lr;
+        const int nrow = (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7);
+        wrow_off[d] = (unsigned)nrow * (unsigned)p.Kbytes + (unsigned)sc * 16u;
+    }
+    // B fragment read address of this lane inside a stage (position 128 wn + 16 j + lrow: + j * 2048), k half 0; k half 1 = ^ 64
+    const unsigned b_lane = (unsigned)((wn * 128 + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
+
+    // ---- per-tile state ------------------------------------------------------------------------------------------------
+    // staging cursor (the tile whose halos are being staged): its group, first row, halo rows of this lane
+
+    unsigned hbase[4];
+    int hiy[4];
+    i32x4 in_srd = w_srd;
+    int st_Hin = 1, st_row_b = 0;
+    auto stage_tile = [&](int T) {                     // T uniform; T >= ntiles: nothing to stage (zeros)
+        if (T >= p.ntiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hiy[i] = -(1 << 28); hbase[i] = 0; }
+            return;
+        }
+        int gi = 0;
+#pragma unroll
+        for (int i = 1; i < RTN_MAX_GROUPS; ++i)
+            if (i < p.ngroups && T >= p.g[i].tile_begin) gi = i;
+
+        const H8Group& Gs = p.g[gi];
+        const int m0 = (T - Gs.tile_begin) * TM;
+        const int cells = Gs.Hin * Gs.Win;
+        in_srd = make_srd(Gs.in, Gs.in_bytes);
+        st_Hin = Gs.Hin;
+        st_row_b = Gs.in_row_stride_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = (i * 8 + wave) * 8 + lr;
+            const int f = m0 + h - p.pad_l;
+            if (h < 255 && f >= 0 && f < Gs.M) {
+                int b, rem, y, x;
+                divmod24(f, cells, Gs.inv_cells, b, rem);
+                divmod24(rem, Gs.Win, Gs.inv_w, y, x);
+                hiy[i] = y;
+                hbase[i] = (unsigned)f * (unsigned)p.pix_b + (unsigned)sc * 16u;
+            } else {
+                hiy[i] = -(1 << 28);
+                hbase[i] = 0;
+            }
+        }
+    };
+    // one halo piece (i) of group (kh, cc) of the staging tile into halo buffer `abuf_addr`
+    auto stage_a = [&](int i, int kh, int cc, unsigned abuf_addr) {
+        const int dy = kh - p.pad_t;
+        const unsigned delta = (unsigned)(dy * st_row_b + cc * 128);
+        const bool ok = (unsigned)(hiy[i] + dy) < (unsigned)st_Hin;
+        dma16(in_srd, ok ? hbase[i] + delta : OOB, 0u, lds_base + abuf_addr + (unsigned)(wave * 1024 + i * 8192));
+    };
+    // one B piece (d) of the K column block `kcol` (bytes) into ring stage `bst`
+    auto stage_b = [&](int d, unsigned kcol, int bst) {
+        dma16(w_srd, wrow_off[d], kcol, lds_base + (unsigned)bst * B_STAGE + (unsigned)(wave * 1024 + d * 8192));
+    };
+
+    // compute tile: A fragment read offsets per tap (k half 0; half 1 = ^ 64), the zero row where the tap leaves the image.
+    // a_cur = LDS offset of the halo buffer the current group reads (toggles per group, also across tiles)
+    unsigned a_cur = A_BASE;
+    unsigned arow[KW][4];
+    auto compute_tile = [&](int T, int& gi_out, int& m0_out) {
+        int gi = 0;
+#pragma unroll
+        for (int i = 1; i < RTN_MAX_GROUPS; ++i)
+            if (i < p.ngroups && T >= p.g[i].tile_begin) gi = i;
+        const H8Group& Gc = p.g[gi];
+        const int m0 = (T - Gc.tile_begin) * TM;
+        const int cells = Gc.Hin * Gc.Win;
+        gi_out = gi;
+        m0_out = m0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rloc = wm * 64 + i * 16 + lrow;
+            const int m = m0 + rloc;
+            const int mc = m < Gc.M ? m : Gc.M - 1;
+            int b, rem, y, x;
+            divmod24(mc, cells, Gc.inv_cells, b, rem);
+            divmod24(rem, Gc.Win, Gc.inv_w, y, x);
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int rr = rloc + kw;
+                const bool off = rloc >= TM || (unsigned)(x + kw - p.pad_l) >= (unsigned)Gc.Win;
+                arow[kw][i] = a_cur + (off ? ZERO_ROW : (unsigned)(rr * 128 + ((kq ^ (rr & 7)) << 4)));
+            }
+        }
+    };
+
+    f32x4 acc[4][8];
+    float bias8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + wn * 128 + 8 * lrow);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + wn * 128 + 8 * lrow + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+
+    // ---- prologue: halo of (tile, group 0), B tiles of steps 0 and 1 (the last piece of step 1 goes out in step 0, phase 1)
+    int tile = blockIdx.x;
+    stage_tile(tile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_a(i, 0, 0, A_BASE);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) stage_b(d, 0u, 0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) stage_b(d, (unsigned)(nchunk * 128), 1);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+
+
+#define H8_LDA(KWI, KS)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
+        fa[i_] = *reinterpret_cast<const uint4*>(lds + (arow[KWI][i_] ^ ((KS) * 64u)));
+#define H8_LDB(KWI, KS, HALF)                                                                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+        fb[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ ((KS) * 64u)) + (KWI) * B_STAGE + ((HALF) * 4 + j_) * 2048);
+#define H8_MFMA(HALF)                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
+            acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_barrier();
+    // One K step = tap KWI of the current group.  DMA slots (see the header): phase 1 the LAST piece of step s+1's B tile,
+    // phases 2-4 the first three pieces of step s+2's, halo pieces of the next group in phases 2 and 4 of taps 0 and 1.
+    // kc_n1 / kc_n2: K column blocks of steps s+1 / s+2.
+#define H8_STEP(KWI)                                                                                 \
+    {                                                                                                \
+        const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
+        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
+        uint4 fa[4], fb[4];                                                                          \
+        /* phase 1 */                                                                                \
+        H8_LDA(KWI, 0) H8_LDB(KWI, 0, 0)                                                             \
+        stage_b(3, kc_n1, ((KWI) + 1) % 3);                                                          \
+        H8_MFMA(0)                                                                                   \
+        /* phase 2 */                                                                                \
+        H8_LDB(KWI, 0, 1)                                                                            \
+        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
+        if ((KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);                                   \
+        H8_MFMA(1)                                                                                   \
+        /* phase 3 */                                                                                \
+        H8_LDA(KWI, 1) H8_LDB(KWI, 1, 0)                                                             \
+        stage_b(1, kc_n2, ((KWI) + 2) % 3);                                                          \
+        H8_MFMA(0)                                                                                   \
+        /* phase 4 */                                                                                \
+        H8_LDB(KWI, 1, 1)                                                                            \
+        stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
+        if ((KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);                               \
+        if ((KWI) < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                              \
+        else           asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                              \
+        H8_MFMA(1)                                                                                   \
+    }
+    static_assert(KW == 3, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3");
+
+    const unsigned kw_stride = (unsigned)(nchunk * 128);           // K bytes between the taps of a kernel row
+    while (tile < p.ntiles) {
+        int gi, m0;
+        compute_tile(tile, gi, m0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
+        int kh = 0, cc = 0;
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            // the next group (kh1, cc1): of this tile, or group 0 of the workgroup's next tile
+            int kh1 = kh, cc1 = cc + 1;
+            if (cc1 == nchunk) { cc1 = 0; ++kh1; }
+            if (g + 1 == G) {
+                kh1 = 0; cc1 = 0;
+                stage_tile(tile + (int)gridDim.x);
+            }
+            const unsigned kcol_g = (unsigned)((kh * KW * nchunk + cc) * 128);
+            const unsigned kcol_g1 = (unsigned)((kh1 * KW * nchunk + cc1) * 128);
+            H8_STEP(0)
+            H8_STEP(1)
+            H8_STEP(2)
+            // next group: the other halo buffer
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) arow[kw][i] ^= A_TOGGLE;
+            a_cur ^= A_TOGGLE;
+            kh = kh1; cc = cc1;
+        }
+        // ---- epilogue: ReLU, bf16, 16 stores of 16 B per lane (rows beyond TM / M go to an out-of-range offset and are dropped)
+        {
+            const H8Group& Gc = p.g[gi];
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
+            const int ncol = wn * 128 + 8 * lrow;
+            const bool col_ok = ncol < p.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rloc = wm * 64 + i * 16 + kq * 4 + r;
+                    const int m = m0 + rloc;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = acc[i][j][r];
+                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                    u32x4 o;
+                    o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+                    const bool ok = col_ok && rloc < TM && m < Gc.M;
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
+                }
+        }
+        tile += (int)gridDim.x;
+        // the staging cursor's halo rows already belong to the next tile (switched in the last group); the pieces it issued for a
+        // tile past the end are zeros from out-of-range offsets
+    }
+#undef H8_STEP
+#undef H8_MFMA
+#undef H8_LDB
+#undef H8_LDA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace
+
+// Launcher.  Returns RTN_OK after a launch, 1 when the layer is not one this kernel takes (the caller falls through to the other
+// kernels), < 0 on a launch error.  `force`: take every eligible layer (tests), otherwise the caller decides.
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger) {
+    if (d->dtype != RTN_BF16) return 1;
+    if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
+    if (d->flags & ~RTN_CONV_RELU) return 1;
+    if (d->N > 256 || d->N <= 128 || d->w_rows != 256 || d->N % 8 || d->out_ld % 8) return 1;
+    if (d->Crun != d->pix_stride || (d->Crun * 2) % 128 || d->Crun <= 0) return 1;
+    if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
+    if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
+    const int nchunk = d->Crun * 2 / 128;
+    const long long Kbytes = (long long)d->KH * d->KW * d->Crun * 2;
+    if (Kbytes * 256 >= 0xFFFFFF00ll) return 1;
+    constexpr int TM = 256 - 3;
+    H8Params p;
+    memset(&p, 0, sizeof(p));
+    long long tiles = 0;
+    for (int i = 0; i < d->ngroups; ++i) {
+        const rtn_conv_group_t& s = d->g[i];
+        if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
+            s.in_img_stride != (long long)s.Hin * s.in_row_stride) return 1;
+        const long long cells = (long long)s.Hout * s.Wout, M = cells * d->batch;
+        if (s.out_step > 1 || s.out_off != 0 || s.out_img_stride != cells * d->out_ld) return 1;      // dense [M][out_ld] output
+        if (M >= (1ll << 24) || M < 1) return 1;
+        if (!s.in || !s.out || ((uintptr_t)s.in & 15) || ((uintptr_t)s.out & 15)) return 1;
+        if (s.in_elems < M * d->Crun || s.out_elems < (M - 1) * d->out_ld + d->N) return 1;
+        if (s.in_elems * 2 >= 0xFFFFFF00ll || s.out_elems * 2 >= 0xFFFFFF00ll) return 1;
+        H8Group& g = p.g[i];
+        g.in = (const char*)s.in;
+        g.out = (char*)s.out;
+        g.in_bytes = (unsigned)(s.in_elems * 2);
+        g.out_bytes = (unsigned)(s.out_elems * 2);
+        g.Hin = s.Hin; g.Win = s.Win; g.M = (int)M;
+        g.tile_begin = (int)tiles;
+        g.in_row_stride_b = (int)(s.in_row_stride * 2);
+        g.inv_cells = 1.0f / (float)cells;
+        g.inv_w = 1.0f / (float)s.Win;
+        tiles += (M + TM - 1) / TM;
+    }
+    if (tiles < 1 || tiles > 0x3fffffff) return 1;
+    p.w = (const char*)d->w;
+    p.bias = d->bias;
+    p.w_bytes = (unsigned)(Kbytes * 256);
+    p.ngroups = d->ngroups;
+    p.ntiles = (int)tiles;
+    p.N = d->N;
+    p.Kbytes = (int)Kbytes;
+    p.KH = d->KH;
+    p.nchunk = nchunk;
+    p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
+    p.out_ld = d->out_ld;
+    p.pix_b = d->pix_stride * 2;
+    int grid = h->num_cus > 0 ? h->num_cus : 256;
+    if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
+    if (grid > p.ntiles) grid = p.ntiles;
+#define RTN_H8_LAUNCH(ST)                                                                                \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, ST>,                        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, ST>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
+    if (stagger) RTN_H8_LAUNCH(true); else RTN_H8_LAUNCH(false);
+#undef RTN_H8_LAUNCH
+    RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
+    return RTN_OK;
+}

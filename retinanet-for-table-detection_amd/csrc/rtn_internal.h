@@ -11,6 +11,7 @@ struct rtn_ctx {
     hipStream_t stream;
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
     int num_cus;
+    int last_conv_impl;     // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
     char err[512];
 };
 
@@ -38,6 +39,10 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
             return rtn_fail((h), RTN_EHIP, "launch of %s failed: %s", name,                \
                             hipGetErrorString(e_));                                        \
     } while (0)
+
+// rtn_conv_halo8.hip: persistent 8-phase kernel for the stride-1 3x3 layers with 129..256 output channels (head towers, P3-P5,
+// res4 branch2b).  RTN_OK = launched, 1 = not a layer this kernel takes, < 0 = error.
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger);
 
 static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }
 

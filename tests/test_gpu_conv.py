@@ -49,7 +49,7 @@ def pack_w(w_hwio, dtype, dev):
 
 
 def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res_mode=None, B=2, seed=0, out_ld=None,
-             concat=False):
+             concat=False, reference=True):
     """levels: list of (H, W). Returns (got list, want list) per level (f64, NHWC)."""
     L = pkg._lib
     dev = torch.device("cuda")
@@ -88,7 +88,7 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
             pt = pl = pad
             Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         d.pad_t, d.pad_l = pt, pl
-        want = ref_conv(q(x, dtype), wq, bias.float().double(), stride, pt, pl, Ho, Wo)
+        want = ref_conv(q(x, dtype), wq, bias.float().double(), stride, pt, pl, Ho, Wo) if reference else torch.zeros(B, Ho, Wo, cout, dtype=torch.float64)
         xd = x.to(tdt).to(dev).contiguous()
         grp = L.ConvGroup()
         grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
@@ -228,6 +228,56 @@ def test_tail_split(pkg, handle, monkeypatch, dtype, impl, levels, cin, cout, k,
     for a, b in zip(gots, gots0):
         assert float((a - b).abs().max()) <= (1e-5 if dtype == "f32" else 4e-2) * max(1.0, float(b.abs().max()))
         assert not torch.equal(a, b) or dtype == "bf16"      # f32: the split changes the summation order somewhere
+
+
+@pytest.mark.parametrize("stagger", [1, 0])
+@pytest.mark.parametrize("levels,cin,cout,relu,B,grid", [
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, True, 2, 0),      # head-tower shape: five levels, one grouped launch
+    ([(40, 67)], 256, 256, False, 3, 3),       # P3-like, no ReLU; 32 tiles on 3 workgroups: every workgroup walks ~11 tiles
+    ([(25, 42), (13, 21)], 128, 200, True, 2, 1),   # two chunks per tap, N not a multiple of 16, ONE workgroup walks all 11 tiles
+    ([(7, 300)], 256, 136, True, 1, 2),        # rows longer than a tile: tiles start and end inside an image row
+    ([(3, 5)], 256, 256, True, 1, 0),          # a single, mostly empty tile
+])
+def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, relu, B, grid, stagger):
+    """Generation 4 (csrc/rtn_conv_halo8.hip): persistent 256 x 256 tiles on the staggered 8-phase schedule, LDS-DMA in flight
+    across barriers behind counted waits, weight rows permuted for a register epilogue.  RTN_CONV_IMPL=4 takes it wherever it
+    applies, RTN_CONV_H8_GRID limits the workgroup count so that workgroups walk several tiles (the halo / B-ring prefetch then
+    crosses tile and pyramid-level boundaries), RTN_CONV_H8_STAGGER=0 runs the two wave groups in lockstep.  Against the float64
+    convolution of the bf16-rounded operands; the launch must really have been generation 4."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "4")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(stagger))
+    flags = L.CONV_RELU if relu else 0
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, None, B=B, seed=90 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
+    check(gots, wants, ld, n, "bf16")
+    # the same layer on generation 3: both are bf16 products summed in f32, in a different order
+    monkeypatch.setenv("RTN_CONV_IMPL", "3")
+    gots3, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, None, B=B, seed=90 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 3
+    for a, b in zip(gots, gots3):
+        assert float((a - b).abs().max()) <= 4e-2 * max(1.0, float(b.abs().max()))
+
+
+def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
+    """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
+    head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "4")
+    levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
+    first = None
+    for it in range(12):
+        monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(1 - it % 2))
+        gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
+                                      reference=(it == 0))
+        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
+        if first is None:
+            check(gots, wants, ld, n, "bf16")
+            first = gots
+        else:
+            for a, b in zip(gots, first):
+                assert torch.equal(a, b), "launch %d differs" % it
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
