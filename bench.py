@@ -42,7 +42,7 @@ GFLOP_PER_IMAGE = 416.1            # 208.06 GMAC forward, ever
 BF16_DENSE_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 CAND_FRACTION = 0.01               # share of anchors above the 0.05 score threshold (set by calibration)
 CLS_BIAS = -5.27                   # default used by tools/ when no calibration runs
-TOWER_KERNEL = "conv_igemm3_kernel<2, 256>"   # symbol of the kernel the launcher picks for the head-tower layers (rtn_conv.hip)
+TOWER_KERNEL = "conv_halo8_kernel<3, true>"   # symbol of the kernel the launcher picks for the head-tower layers (rtn_conv_halo8.hip)
 
 
 def synth_images(torch, B, seed, device):

@@ -1418,15 +1418,17 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     // kernel wherever it applies, 0 disables it.
     const int halo_env = rtn_env_int("RTN_CONV_HALO", 1);
     if (impl == 2 && halo_ok && rtn_conv_impl_override() == 0 && (halo_env == 2 || (halo_env == 1 && d->N >= 256 && bn2 == 256))) impl = 3;
-    // Fourth generation (rtn_conv_halo8.hip): the layers generation 3 runs on 256-wide tiles (the grouped head towers, P3),
-    // persistent and on the staggered 8-phase schedule.  RTN_CONV_H8=0 keeps generation 3, 2 takes every layer the kernel accepts
-    // (as RTN_CONV_IMPL=4 does); RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers),
-    // RTN_CONV_H8_STAGGER=0 runs the two wave groups in lockstep (A/B).
+    // Fourth generation (rtn_conv_halo8.hip): every stride-1 3x3 bf16 layer with 129..256 output channels and a bias/ReLU epilogue
+    // (the grouped head towers, P3-P5, res4 branch2b), persistent and on the staggered 8-phase schedule.  Measured against
+    // generation 3 / 2 in one process (tools/ab_conv.py): head layer 0.225 -> 0.150 ms, P3 0.201 -> 0.150, res4 3x3 0.063 -> 0.049,
+    // P4 0.062 -> 0.047.  RTN_CONV_H8=0 turns it off (A/B), RTN_CONV_IMPL=4 forces it like any other generation;
+    // RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers), RTN_CONV_H8_STAGGER=0 runs
+    // the two wave groups in lockstep (A/B: 0.181 ms on the head layer).
     if (!query && !s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16) {
         const int h8 = rtn_env_int("RTN_CONV_H8", 1);
         const int forced = rtn_conv_impl_override();
-        if ((forced == 4 || (forced == 0 && (h8 == 2 || (h8 == 1 && impl == 3 && bn2 == 256))))) {
-            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0);
+        if (forced == 4 || (forced == 0 && h8 != 0)) {
+            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4);
             if (rc == RTN_OK) h->last_conv_impl = 4;
             if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
         }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 
 // Launcher.  Returns RTN_OK after a launch, 1 when the layer is not one this kernel takes (the caller falls through to the other
 // kernels), < 0 on a launch error.  `force`: take every eligible layer (tests), otherwise the caller decides.
-int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger) {
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced) {
     if (d->dtype != RTN_BF16) return 1;
     if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
     if (d->flags & ~RTN_CONV_RELU) return 1;
@@ -386,6 +386,10 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         tiles += (M + TM - 1) / TM;
     }
     if (tiles < 1 || tiles > 0x3fffffff) return 1;
+    // one 256 x 256 tile per CU: below a quarter of the chip the narrow tiles of generation 2 (four times the workgroups) are
+    // faster (P5 at batch 8: 34 tiles, 0.049 ms here against 0.037 ms); from half the chip on this kernel wins (res4 3x3, P4:
+    // 133 tiles, 0.054 against 0.067 ms)
+    if (!forced && tiles * 4 < (h->num_cus > 0 ? h->num_cus : 256)) return 1;
     p.w = (const char*)d->w;
     p.bias = d->bias;
     p.w_bytes = (unsigned)(Kbytes * 256);
