@@ -73,6 +73,15 @@ class AnchorCfg(C.Structure):
     ]
 
 
+class BottleneckDesc(C.Structure):
+    _fields_ = [
+        ("a_in", C.c_void_p), ("a_in_elems", C.c_int64), ("x_in", C.c_void_p), ("x_in_elems", C.c_int64),
+        ("x_out", C.c_void_p), ("x_out_elems", C.c_int64), ("a_out", C.c_void_p), ("a_out_elems", C.c_int64),
+        ("w2b", C.c_void_p), ("b2b", C.c_void_p), ("w2c", C.c_void_p), ("b2c", C.c_void_p), ("w2a", C.c_void_p), ("b2a", C.c_void_p),
+        ("batch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("mid", C.c_int32), ("dtype", C.c_int32), ("reserved_", C.c_int32),
+    ]
+
+
 class ConvFp8(C.Structure):
     _fields_ = [("acc_scale", C.c_float), ("out_scale", C.c_float), ("out_dtype", C.c_int32)]
 
@@ -90,6 +99,7 @@ SIGNATURES = {
     "rtn_debug_last_conv_impl": (_I, [_P]),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
+    "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_pack_dgrad_weights_multi": (_I, [_P, _P, _I, _I64, _I]),

@@ -1,0 +1,319 @@
+// rtn_bottleneck.hip — a keras_resnet identity bottleneck block of the 64-channel stage as ONE kernel:
+//   branch2b (3x3, 64 -> 64, BN, ReLU) -> branch2c (1x1, 64 -> 256, BN) + shortcut + ReLU -> [next block's branch2a (1x1, 256 -> 64, BN, ReLU)]
+// (keras_resnet bottleneck_2d, called from model/defineModel.py:376-380; the reference executes these as three Conv2D ops, three
+// BatchNormalization ops, an Add and three ReLUs.)  res2 is HBM-bound: unfused, a block moves 1.09 GB at batch 8 (the 64-channel
+// tensors twice each, the 256-channel tensor four times); fused it reads the 64-channel input and the shortcut once and writes the
+// 256-channel output and the next block's 64-channel input once: 0.68 GB.
+//
+// How the three GEMMs chain without LDS or barriers: every product is computed TRANSPOSED, D^T[channel][pixel] = W[channel][k] .
+// X^T[k][pixel] — the weights are the MFMA's A operand (LDS-resident for the whole kernel), the pixels its columns.  In the
+// 16x16x32 layout a lane (q, c) then owns, per 16-channel fragment, 4 consecutive channel ROWS of pixel c — and the B operand of the
+// next product wants, from lane (kq = q, column c), 8 consecutive k of pixel c.  With the weight rows of each product stored
+// permuted (row 16 f + 4 q + r  <->  channel 32 (f >> 1) + 8 q + 4 (f & 1) + r) two fragments of a lane ARE those 8 values: bias,
+// ReLU, pack to bf16, and the accumulators of one product are the next product's B operand in place (cdna_hip_programming.md §3,
+// "An accumulator tile as the next MFMA's operand").  The same registers are what is stored: 16 bytes = 8 consecutive channels.
+//
+// Work decomposition: a wave owns a strip of 32 consecutive pixels (two 16-pixel column fragments) and runs the whole chain on it;
+// waves never synchronise (the only shared data, the weights, is read-only).  The 3x3's input fragments come straight from global
+// memory (16 B per lane: pixel x tap x 8 channels; padding taps get an out-of-range buffer offset = zeros), the shortcut likewise.
+// LDS: 17 weight images of [64 rows][128 B] (9 taps of W2b, 4 output chunks of W2c, 4 k-chunks of W2a') + biases = 137.5 KiB.
+#include "rtn_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr unsigned BK_OOB = 0xFFFF0000u;       // beyond every descriptor (< 2 GiB) even with the largest uniform offset added
+constexpr int BK_THREADS = 512;
+constexpr int IMG = 64 * 128;                          // one weight image: 64 rows x 128 B
+constexpr int W2B_OFF = 0, W2C_OFF = 9 * IMG, W2A_OFF = 13 * IMG, BIAS_OFF = 17 * IMG;
+constexpr int BK_LDS = BIAS_OFF + (64 + 256 + 64) * 4;
+
+struct BkParams {
+    const char* ain;        // [M][64]  bf16: this block's branch2a output (after BN + ReLU)
+    const char* xin;        // [M][256] bf16: the block input (identity shortcut)
+    char* xout;             // [M][256] bf16
+    char* aout;             // [M][64]  bf16 or nullptr: the next block's branch2a output
+    const char* w2b;        // [64][3*3*64] bf16, BN folded
+    const char* w2c;        // [256][64]
+    const char* w2a;        // [64][256] (next block), or nullptr
+    const float* b2b;       // [64], [256], [64] f32 (folded BN shifts)
+    const float* b2c;
+    const float* b2a;
+    int M, H, W, nstrips;
+    float inv_cells, inv_w;
+};
+
+__device__ __forceinline__ int perm_row(int rho) {     // MFMA row (16 f + 4 q + r) -> channel 32 (f >> 1) + 8 q + 4 (f & 1) + r
+    const int f = rho >> 4, q = (rho >> 2) & 3, r = rho & 3;
+    return 32 * (f >> 1) + 8 * q + 4 * (f & 1) + r;
+}
+
+__device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r) {
+    q = (int)((float)f * inv);
+    r = f - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <bool TAIL>
+__global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, q = lane >> 4;            // column (pixel) / k quarter = row quarter of this lane
+
+    // ---- weights -> LDS, once: image row rho holds source row perm_row(rho); 16-byte chunk s of a row sits at slot s ^ (rho & 7)
+    {
+        const int rho = t >> 3, slot = t & 7, chunk = slot ^ (rho & 7), src = perm_row(rho);
+#pragma unroll 1
+        for (int im = 0; im < 17; ++im) {
+            const char* g = nullptr;
+            if (im < 9)       g = p.w2b + ((long long)src * 576 + im * 64) * 2 + chunk * 16;
+            else if (im < 13) g = p.w2c + ((long long)((im - 9) * 64 + src) * 64) * 2 + chunk * 16;
+            else if (TAIL)    g = p.w2a + ((long long)src * 256 + (im - 13) * 64) * 2 + chunk * 16;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (g) v = *reinterpret_cast<const uint4*>(g);
+            *reinterpret_cast<uint4*>(lds + im * IMG + rho * 128 + slot * 16) = v;
+        }
+        float* bl = reinterpret_cast<float*>(lds + BIAS_OFF);
+        if (t < 64) bl[t] = p.b2b[t];
+        if (t < 256) bl[64 + t] = p.b2c[t];
+        if (t < 64) bl[320 + t] = TAIL ? p.b2a[t] : 0.f;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.ain, 0, p.M * 128, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.xin, 0, p.M * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.xout, 0, p.M * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t n_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? p.aout : p.xout), 0, TAIL ? p.M * 128 : 0, 0x00020000);
+
+    // A-operand (weight) fragment of image `im`, row fragment f, k half ks: lane (kq = q, row c) reads row 16 f + c
+    const unsigned w_lane = (unsigned)(c * 128 + ((q ^ (c & 7)) << 4));
+#define BK_WFRAG(IMOFF, F, KS) (*reinterpret_cast<const uint4*>(lds + (IMOFF) + (F) * 2048 + (w_lane ^ ((KS) * 64u))))
+    const float* bias_l = reinterpret_cast<const float*>(lds + BIAS_OFF);
+    // bias of this lane's rows of fragment f (channels 32 (f >> 1) + 8 q + 4 (f & 1) + r, r = 0..3: one float4)
+#define BK_BIAS(BASE, F) (*reinterpret_cast<const f32x4*>(bias_l + (BASE) + 32 * ((F) >> 1) + 8 * q + 4 * ((F) & 1)))
+#define BK_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
+
+    const int cells = p.H * p.W;
+    const int stride = (int)gridDim.x * (BK_THREADS / 64);
+#pragma unroll 1
+    for (int strip = (int)blockIdx.x * (BK_THREADS / 64) + wave; strip < p.nstrips; strip += stride) {
+        const int p0 = strip * 32;
+        // ---- this lane's two pixels, their image position, the byte offsets of the 9 taps (out-of-image taps: zeros)
+        unsigned pbase[2];          // byte offset of the pixel in a 64-channel tensor (+ this lane's 8-channel group)
+        unsigned okmask[2];         // bit (kh * 3 + kw): the tap lies inside the image
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pix = p0 + 16 * u + c;
+            live[u] = pix < p.M;
+            const int pc = live[u] ? pix : p.M - 1;
+            int b, rem, y, x;
+            divmod24(pc, cells, p.inv_cells, b, rem);
+            divmod24(rem, p.W, p.inv_w, y, x);
+            unsigned m = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    if (live[u] && (unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) m |= 1u << (kh * 3 + kw);
+            okmask[u] = m;
+            pbase[u] = (unsigned)pc * 128u + (unsigned)q * 16u;
+        }
+        // ---- G1: branch2b.  acc1[f][u] = sum over taps, k of W2b[chan(f)][tap][k] * Ain[pixel(u) + tap][k]
+        f32x4 acc1[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const f32x4 bv = BK_BIAS(0, f);
+            acc1[f][0] = bv; acc1[f][1] = bv;
+        }
+        // tap by tap: the 4 fragment loads of tap t + 1 are issued before the 16 MFMAs of tap t (two register sets; the
+        // scheduling fences keep hipcc from hoisting all 36 loads of the strip to the top, which spilled 490 registers)
+#define BK_LOAD_TAP(T, DST)                                                                          \
+    {                                                                                                \
+        const int delta_ = (((T) / 3 - 1) * p.W + ((T) % 3 - 1)) * 128;                              \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
+            const unsigned off_ = ((okmask[u_] >> (T)) & 1u) ? pbase[u_] + (unsigned)delta_ : BK_OOB; \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                    \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off_, ks_ * 64, 0); \
+                DST[ks_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                   \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#define BK_MUL_TAP(T, SRC)                                                                           \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                              \
+        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                           \
+            const uint4 wf_ = BK_WFRAG(W2B_OFF + (T) * IMG, f_, ks_);                                \
+            BK_MFMA(acc1[f_][0], wf_, SRC[ks_][0]);                                                  \
+            BK_MFMA(acc1[f_][1], wf_, SRC[ks_][1]);                                                  \
+        }
+        {
+            uint4 xa[2][2], xb[2][2];      // [k half][u], ping-pong
+            BK_LOAD_TAP(0, xa)
+#pragma unroll
+            for (int tp = 0; tp < 9; tp += 2) {
+                if (tp + 1 < 9) BK_LOAD_TAP(tp + 1, xb)
+                __builtin_amdgcn_sched_barrier(0);
+                BK_MUL_TAP(tp, xa)
+                __builtin_amdgcn_sched_barrier(0);
+                if (tp + 1 < 9) {
+                    if (tp + 2 < 9) BK_LOAD_TAP(tp + 2, xa)
+                    __builtin_amdgcn_sched_barrier(0);
+                    BK_MUL_TAP(tp + 1, xb)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#undef BK_MUL_TAP
+#undef BK_LOAD_TAP
+        // ReLU + bf16: the B operand of G2, k half s = fragments 2 s and 2 s + 1
+        uint4 h1[2][2];             // [s][u]
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 lo = acc1[2 * s][u], hi = acc1[2 * s + 1][u];
+                h1[s][u] = make_uint4(pack2(relu(lo[0]), relu(lo[1])), pack2(relu(lo[2]), relu(lo[3])),
+                                      pack2(relu(hi[0]), relu(hi[1])), pack2(relu(hi[2]), relu(hi[3])));
+            }
+        // ---- G2 (branch2c + shortcut + ReLU) in four 64-channel chunks, each feeding G3 (next branch2a) as one k chunk
+        f32x4 acc3[4][2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const f32x4 bv = BK_BIAS(320, f);
+            acc3[f][0] = bv; acc3[f][1] = bv;
+        }
+        const unsigned xoff[2] = {live[0] ? (unsigned)(p0 + c) * 512u + (unsigned)q * 16u : BK_OOB,
+                                  live[1] ? (unsigned)(p0 + 16 + c) * 512u + (unsigned)q * 16u : BK_OOB};
+#define BK_LOAD_RES(G, DST)                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u_], (G) * 128 + s_ * 64, 0); \
+            DST[s_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                        \
+        }
+        uint4 resq[2][2][2];        // [parity][s][u]: shortcut, channels 64 g + 32 s + 8 q .. + 8 of pixel (u, c); chunk g + 1 in flight
+        BK_LOAD_RES(0, resq[0])
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) BK_LOAD_RES(g + 1, resq[(g + 1) & 1])
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 (&res)[2][2] = resq[g & 1];
+            f32x4 acc2[4][2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const f32x4 bv = BK_BIAS(64 + 64 * g, f);
+                acc2[f][0] = bv; acc2[f][1] = bv;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const uint4 wf = BK_WFRAG(W2C_OFF + g * IMG, f, ks);
+                    BK_MFMA(acc2[f][0], wf, h1[ks][0]);
+                    BK_MFMA(acc2[f][1], wf, h1[ks][1]);
+                }
+            uint4 xo[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 lo = acc2[2 * s][u], hi = acc2[2 * s + 1][u];
+                    const uint4 r = res[s][u];
+                    const uint4 o = make_uint4(pack2(relu(lo[0] + bf_lo(r.x)), relu(lo[1] + bf_hi(r.x))),
+                                               pack2(relu(lo[2] + bf_lo(r.y)), relu(lo[3] + bf_hi(r.y))),
+                                               pack2(relu(hi[0] + bf_lo(r.z)), relu(hi[1] + bf_hi(r.z))),
+                                               pack2(relu(hi[2] + bf_lo(r.w)), relu(hi[3] + bf_hi(r.w))));
+                    xo[s][u] = o;
+                    const u32x4 ov = {o.x, o.y, o.z, o.w};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)xoff[u], g * 128 + s * 64, 0);
+                }
+            if (TAIL) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const uint4 wf = BK_WFRAG(W2A_OFF + g * IMG, f, ks);
+                        BK_MFMA(acc3[f][0], wf, xo[ks][0]);
+                        BK_MFMA(acc3[f][1], wf, xo[ks][1]);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef BK_LOAD_RES
+        if (TAIL) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 lo = acc3[2 * s][u], hi = acc3[2 * s + 1][u];
+                    const u32x4 ov = {pack2(relu(lo[0]), relu(lo[1])), pack2(relu(lo[2]), relu(lo[3])),
+                                      pack2(relu(hi[0]), relu(hi[1])), pack2(relu(hi[2]), relu(hi[3]))};
+                    const unsigned off = live[u] ? (unsigned)(p0 + 16 * u + c) * 128u + (unsigned)q * 16u : BK_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, n_rsrc, (int)off, s * 64, 0);
+                }
+        }
+    }
+#undef BK_MFMA
+#undef BK_BIAS
+#undef BK_WFRAG
+}
+
+}  // namespace
+
+extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d) {
+    if (!h) return RTN_EINVAL;
+    if (!d) return rtn_fail(h, RTN_EINVAL, "bottleneck64: null descriptor");
+    if (d->dtype != RTN_BF16) return rtn_fail(h, RTN_EINVAL, "bottleneck64: bf16 only");
+    if (d->mid != 64) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the fused block exists for 64 bottleneck channels (res2), got %d", d->mid);
+    if (d->batch < 1 || d->H < 1 || d->W < 1) return rtn_fail(h, RTN_EINVAL, "bottleneck64: empty extent");
+    const long long M = (long long)d->batch * d->H * d->W;
+    if (M >= (1ll << 22)) return rtn_fail(h, RTN_EINVAL, "bottleneck64: %lld pixels exceed the 4 Mi-pixel (2 GiB tensor) range", M);
+    const void* need[] = {d->a_in, d->x_in, d->x_out, d->w2b, d->w2c, d->b2b, d->b2c};
+    for (const void* q : need)
+        if (!q || ((uintptr_t)q & 15)) return rtn_fail(h, RTN_EINVAL, "bottleneck64: null / misaligned pointer");
+    const bool tail = d->a_out != nullptr;
+    if (tail && (!d->w2a || !d->b2a || ((uintptr_t)d->a_out & 15) || ((uintptr_t)d->w2a & 15) || ((uintptr_t)d->b2a & 15)))
+        return rtn_fail(h, RTN_EINVAL, "bottleneck64: a_out needs aligned w2a / b2a");
+    if (d->a_in_elems < M * 64 || d->x_in_elems < M * 256 || d->x_out_elems < M * 256 || (tail && d->a_out_elems < M * 64))
+        return rtn_fail(h, RTN_EBOUNDS, "bottleneck64: a tensor is smaller than batch x H x W x channels");
+    if (d->x_out == d->x_in || d->x_out == d->a_in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the output may not alias an input (taps of neighbouring strips)");
+    BkParams p;
+    memset(&p, 0, sizeof(p));
+    p.ain = (const char*)d->a_in; p.xin = (const char*)d->x_in; p.xout = (char*)d->x_out; p.aout = (char*)d->a_out;
+    p.w2b = (const char*)d->w2b; p.w2c = (const char*)d->w2c; p.w2a = (const char*)d->w2a;
+    p.b2b = d->b2b; p.b2c = d->b2c; p.b2a = d->b2a;
+    p.M = (int)M; p.H = d->H; p.W = d->W;
+    p.nstrips = (int)((M + 31) / 32);
+    p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
+    p.inv_w = 1.0f / (float)d->W;
+    int grid = h->num_cus > 0 ? h->num_cus : 256;
+    const int wgs_needed = (p.nstrips + 7) / 8;
+    if (grid > wgs_needed) grid = wgs_needed;
+#define RTN_BK_LAUNCH(T)                                                                                 \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T>,                          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((bottleneck64_kernel<T>), dim3((unsigned)grid), dim3(BK_THREADS), BK_LDS, h->stream, p); \
+    } while (0)
+    if (tail) RTN_BK_LAUNCH(true); else RTN_BK_LAUNCH(false);
+#undef RTN_BK_LAUNCH
+    RTN_CHECK_LAUNCH(h, "bottleneck64_kernel");
+    return RTN_OK;
+}

@@ -86,6 +86,9 @@ class Engine:
         self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
         self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
         self.fuse_shortcut = os.environ.get("RTN_FUSE_SHORTCUT", "1") != "0"  # inference: branch1 folded into branch2c (dual-source GEMM)
+        # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
+        # + shortcut -> the next block's branch2a)
+        self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
         self.weights_version = 0
         self.load_epoch = 0            # bumped by load_state(): a live Trainer re-derives its master copy / plans from it
         self._dual, self._dual_version = {}, -1
@@ -293,6 +296,27 @@ class Engine:
         s2.Hin, s2.Win, s2.C, s2.step = x.shape[1], x.shape[2], x.shape[3], fb["step"]
         return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
+    def _bneck_op(self, blk, nxt, B):
+        """An identity block of the 64-channel stage as one launch (rtn_bottleneck64_fwd): branch2b + branch2c + Add + ReLU of
+        `blk`, and branch2a of the following identity block `nxt` when there is one."""
+        w2b, b2b = self.w[blk["n2b"]][:2]
+        w2c, b2c = self.w[blk["n2c"]][:2]
+        a, x, y = blk["a"], blk["x"], blk["y"]
+        d = L.BottleneckDesc()
+        d.a_in, d.a_in_elems = a.data_ptr(), a.numel()
+        d.x_in, d.x_in_elems = x.data_ptr(), x.numel()
+        d.x_out, d.x_out_elems = y.data_ptr(), y.numel()
+        d.w2b, d.b2b, d.w2c, d.b2c = w2b.data_ptr(), b2b.data_ptr(), w2c.data_ptr(), b2c.data_ptr()
+        outs = [y]
+        if nxt is not None:
+            w2a, b2a = self.w[nxt["n2a"]][:2]
+            d.a_out, d.a_out_elems = nxt["a"].data_ptr(), nxt["a"].numel()
+            d.w2a, d.b2a = w2a.data_ptr(), b2a.data_ptr()
+            outs.append(nxt["a"])
+        d.batch, d.H, d.W, d.mid, d.dtype = B, blk["Ho"], blk["Wo"], 64, self.rdt
+        name = blk["n2b"] + "+2c" + ("+next2a" if nxt is not None else "")
+        return ("bneck", d, name, {"xs": [a, x], "ys": outs, "B": B, "H": blk["Ho"], "W": blk["Wo"], "tail": nxt is not None})
+
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W):
         fp8_on = self._fp8_on()
@@ -349,6 +373,7 @@ class Engine:
         # ---- bottleneck stages
         feats = []
         first_blocks = []
+        blocks64 = []                    # identity blocks of the 64-channel stage: candidates for the fused bottleneck kernel
         a_acts = {}
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
             f = 64 * 2 ** stage
@@ -367,10 +392,14 @@ class Engine:
                 else:
                     a = buf(B, Ho, Wo, f)
                     ops.append(self._conv(n2a, [self._group(x, a, Ho, Wo)], B, stride=st, flags=L.CONV_RELU))
+                    i_2a = len(ops) - 1
                     b2 = buf(B, Ho, Wo, f)
                     ops.append(self._conv(n2b, [self._group(a, b2, Ho, Wo)], B, pad=(1, 1), flags=L.CONV_RELU))
                     if f >= 128:
                         a_acts[n2a] = a
+                    if f == 64 and block > 0:
+                        blocks64.append({"block": block, "i_2a": i_2a, "i_2b": len(ops) - 1, "a": a, "x": x, "n2a": n2a, "n2b": n2b,
+                                         "n2c": "res%s%s_branch2c" % (s, bname), "Ho": Ho, "Wo": Wo})
                 if block == 0:
                     sc = buf(B, Ho, Wo, 4 * f)
                     ops.append(self._conv("res%s%s_branch1" % (s, bname), [self._group(x, sc, Ho, Wo)], B, stride=st))
@@ -383,6 +412,8 @@ class Engine:
                 if block == 0:
                     first_blocks.append({"key": "res%s%s" % (s, bname), "i_b1": i_b1, "i_2c": len(ops) - 1, "x": x, "b2": b2, "y": y,
                                          "Ho": Ho, "Wo": Wo, "step": st, "f": f})
+                if blocks64 and blocks64[-1].get("y") is None and blocks64[-1]["n2c"] == "res%s%s_branch2c" % (s, bname):
+                    blocks64[-1].update({"i_2c": len(ops) - 1, "y": y})
                 x = y
             feats.append(x)
         C3, C4, C5 = feats[1], feats[2], feats[3]
@@ -461,19 +492,28 @@ class Engine:
         ws_bytes = L.lib.rtn_detect_workspace_bytes(B, N, self.K)
         sched = self._schedule(ops)
         variants = {}
+        bneck_ok = self.dtype == "bf16" and not fp8_on
         for fs in (False, True):                         # fuse_stem
             for fd in (False, True):                     # fuse_shortcut
-                if not fs and not fd:
-                    continue
-                v = list(ops)
-                if fd:
-                    for fb in first_blocks:
-                        v[fb["i_2c"]] = self._dual_op(fb, B)
-                        v[fb["i_b1"]] = None
-                if fs:
-                    v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
-                v = [op for op in v if op is not None]
-                variants[(fs, fd)] = (v, self._schedule(v))
+                for fk in ((False, True) if bneck_ok else (False,)):      # fuse_bottleneck
+                    if not fs and not fd and not fk:
+                        continue
+                    v = list(ops)
+                    if fd:
+                        for fb in first_blocks:
+                            v[fb["i_2c"]] = self._dual_op(fb, B)
+                            v[fb["i_b1"]] = None
+                    if fk:
+                        for bi, blk in enumerate(blocks64):
+                            nxt = blocks64[bi + 1] if bi + 1 < len(blocks64) else None      # its branch2a rides along
+                            v[blk["i_2b"]] = self._bneck_op(blk, nxt, B)
+                            v[blk["i_2c"]] = None
+                            if nxt is not None:
+                                v[nxt["i_2a"]] = None
+                    if fs:
+                        v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
+                    v = [op for op in v if op is not None]
+                    variants[(fs, fd, fk)] = (v, self._schedule(v))
         plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "a_acts": a_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
@@ -500,6 +540,8 @@ class Engine:
             return [op[5].data_ptr()], [op[1].data_ptr()]
         if kind == "dual":
             return [t.data_ptr() for t in op[4]["xs"]], [t.data_ptr() for t in op[4]["ys"]]
+        if kind == "bneck":
+            return [t.data_ptr() for t in op[3]["xs"]], [t.data_ptr() for t in op[3]["ys"]]
         if kind == "pool":
             return [op[1].data_ptr()], [op[2].data_ptr(), op[4].data_ptr()]
         if kind == "relu":
@@ -615,10 +657,12 @@ class Engine:
         return plan["regression"], plan["classification"]
 
     def _fused(self):
-        """(stem fused, shortcut fused) or None.  Training keeps conv1 / pool1 separate (the backward needs conv1's output and
-        the pooling argmax); the folded shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and
-        filters.  The fused stem exists for bf16 only."""
-        key = (self.fuse_stem and self.dtype == "bf16" and not self.training, self.fuse_shortcut)
+        """(stem fused, shortcut fused, 64-channel bottleneck blocks fused) or None.  Training keeps conv1 / pool1 separate (the
+        backward needs conv1's output and the pooling argmax) and every bottleneck tensor (the backward reads them); the folded
+        shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and filters.  The fused stem and the fused
+        bottleneck exist for bf16 only; the fp8 plan keeps its own branch2a / branch2b pairing."""
+        infer16 = self.dtype == "bf16" and not self.training
+        key = (self.fuse_stem and infer16, self.fuse_shortcut, self.fuse_bottleneck and infer16 and not self._fp8_on())
         return key if any(key) else None
 
     def active_ops(self, plan):
@@ -633,6 +677,8 @@ class Engine:
             h.check(lib.rtn_conv2d_fwd(h.raw, C.byref(op[1])))
         elif kind == "dual":
             h.check(lib.rtn_conv1x1_dual_fwd(h.raw, C.byref(op[1]), C.byref(op[3])))
+        elif kind == "bneck":
+            h.check(lib.rtn_bottleneck64_fwd(h.raw, C.byref(op[1])))
         elif kind == "conv8":
             h.check(lib.rtn_conv2d_fp8_fwd(h.raw, C.byref(op[1]), C.byref(op[4])))
         elif kind == "convq":
