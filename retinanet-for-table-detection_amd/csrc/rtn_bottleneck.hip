@@ -18,6 +18,7 @@
 // memory (16 B per lane: pixel x tap x 8 channels; padding taps get an out-of-range buffer offset = zeros), the shortcut likewise.
 // LDS: 17 weight images of [64 rows][128 B] (9 taps of W2b, 4 output chunks of W2c, 4 k-chunks of W2a') + biases = 137.5 KiB.
 #include "rtn_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,7 +28,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr unsigned BK_OOB = 0xFFFF0000u;       // beyond every descriptor (< 2 GiB) even with the largest uniform offset added
-constexpr int BK_THREADS = 512;
 constexpr int IMG = 64 * 128;                          // one weight image: 64 rows x 128 B
 constexpr int W2B_OFF = 0, W2C_OFF = 9 * IMG, W2A_OFF = 13 * IMG, BIAS_OFF = 17 * IMG;
 constexpr int BK_LDS = BIAS_OFF + (64 + 256 + 64) * 4;
@@ -45,6 +45,8 @@ struct BkParams {
     const float* b2a;
     int M, H, W, nstrips;
     float inv_cells, inv_w;
+    int phase_sleep;        // start delay per wave index, in units of 64 cycles (see the de-phasing note in the kernel)
+    int dbg;                // timing ablation only (RTN_BNECK_DBG): 1 drop the 3x3's loads, 2 the shortcut loads, 4 the x_out stores, 8 the a_out stores
 };
 
 __device__ __forceinline__ int perm_row(int rho) {     // MFMA row (16 f + 4 q + r) -> channel 32 (f >> 1) + 8 q + 4 (f & 1) + r
@@ -67,8 +69,8 @@ __device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <bool TAIL>
-__global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkParams p) {
+template <bool TAIL, int BK_THREADS, bool ROWPP>
+__global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_kernel(const BkParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
 
     // ---- weights -> LDS, once: image row rho holds source row perm_row(rho); 16-byte chunk s of a row sits at slot s ^ (rho & 7)
     {
-        const int rho = t >> 3, slot = t & 7, chunk = slot ^ (rho & 7), src = perm_row(rho);
+        const int rho = (t >> 3) & 63, slot = t & 7, chunk = slot ^ (rho & 7), src = perm_row(rho);
 #pragma unroll 1
-        for (int im = 0; im < 17; ++im) {
+        for (int im = 0; im < 17 && t < 512; ++im) {
             const char* g = nullptr;
             if (im < 9)       g = p.w2b + ((long long)src * 576 + im * 64) * 2 + chunk * 16;
             else if (im < 13) g = p.w2c + ((long long)((im - 9) * 64 + src) * 64) * 2 + chunk * 16;
@@ -109,18 +111,21 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
 
     const int cells = p.H * p.W;
     const int stride = (int)gridDim.x * (BK_THREADS / 64);
-#pragma unroll 1
-    for (int strip = (int)blockIdx.x * (BK_THREADS / 64) + wave; strip < p.nstrips; strip += stride) {
-        const int p0 = strip * 32;
-        // ---- this lane's two pixels, their image position, the byte offsets of the 9 taps (out-of-image taps: zeros)
+    // strips are dealt wave-major: the one or two extra strips of a launch go to the low wave indices of every workgroup
+    // ---- geometry of a strip for this lane: its two pixels, the byte offsets of their taps, the shortcut / output offsets
+    struct Geo {
         unsigned pbase[2];          // byte offset of the pixel in a 64-channel tensor (+ this lane's 8-channel group)
         unsigned okmask[2];         // bit (kh * 3 + kw): the tap lies inside the image
-        bool live[2];
+        unsigned xoff[2];           // byte offset in a 256-channel tensor (+ this lane's 8-channel group), out of range past M
+        unsigned aoff[2];           // byte offset in the 64-channel output
+    };
+    auto geometry = [&](int strip, Geo& g) {
+        const int p0 = strip * 32;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pix = p0 + 16 * u + c;
-            live[u] = pix < p.M;
-            const int pc = live[u] ? pix : p.M - 1;
+            const bool live = strip < p.nstrips && pix < p.M;
+            const int pc = live ? pix : 0;
             int b, rem, y, x;
             divmod24(pc, cells, p.inv_cells, b, rem);
             divmod24(rem, p.W, p.inv_w, y, x);
@@ -129,10 +134,51 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
-                    if (live[u] && (unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) m |= 1u << (kh * 3 + kw);
-            okmask[u] = m;
-            pbase[u] = (unsigned)pc * 128u + (unsigned)q * 16u;
+                    if (live && (unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) m |= 1u << (kh * 3 + kw);
+            g.okmask[u] = (p.dbg & 1) ? 0u : m;
+            g.pbase[u] = (unsigned)pc * 128u + (unsigned)q * 16u;
+            g.xoff[u] = live ? (unsigned)pix * 512u + (unsigned)q * 16u : BK_OOB;
+            g.aoff[u] = (live && !(p.dbg & 8)) ? (unsigned)pix * 128u + (unsigned)q * 16u : BK_OOB;
         }
+    };
+#define BK_LOAD_ROW(KH, G, DST)                                                                      \
+    _Pragma("unroll") for (int kw_ = 0; kw_ < 3; ++kw_) {                                            \
+        const int delta_ = (((KH) - 1) * p.W + (kw_ - 1)) * 128;                                     \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
+            const unsigned off_ = ((G.okmask[u_] >> ((KH) * 3 + kw_)) & 1u) ? G.pbase[u_] + (unsigned)delta_ : BK_OOB; \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                    \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off_, ks_ * 64, 0); \
+                DST[kw_][ks_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                              \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#define BK_MUL_ROW(KH, SRC)                                                                          \
+    _Pragma("unroll") for (int kw_ = 0; kw_ < 3; ++kw_)                                              \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
+            _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                       \
+                const uint4 wf_ = BK_WFRAG(W2B_OFF + ((KH) * 3 + kw_) * IMG, f_, ks_);               \
+                BK_MFMA(acc1[f_][0], wf_, SRC[kw_][ks_][0]);                                         \
+                BK_MFMA(acc1[f_][1], wf_, SRC[kw_][ks_][1]);                                         \
+            }
+#define BK_LOAD_RES(GI, G, DST)                                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((p.dbg & 2) ? BK_OOB : G.xoff[u_]), (GI) * 128 + s_ * 64, 0); \
+            DST[s_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                        \
+        }
+    // Software pipeline over the strips of this wave.  vmcnt retires in order, so a load can only be waited for together with
+    // every store issued before it: the first tap row and the first shortcut chunk of the NEXT strip are therefore requested in
+    // the middle of the current strip's output chunks (before the stores of chunks 2 and 3), not after them - otherwise every
+    // strip begins by waiting for its predecessor's 20 stores to be acknowledged (measured: memory and compute times added up).
+    Geo gc, gn;
+    uint4 row0[3][2][2];            // [kw][k half][u]: tap row 0 of the current strip (requested during the previous strip)
+    uint4 res0[2][2];               // shortcut chunk 0 of the current strip (likewise)
+    int strip = wave * (int)gridDim.x + (int)blockIdx.x;
+    geometry(strip, gc);
+    BK_LOAD_ROW(0, gc, row0)
+    BK_LOAD_RES(0, gc, res0)
+#pragma unroll 1
+    for (; strip < p.nstrips; strip += stride) {
         // ---- G1: branch2b.  acc1[f][u] = sum over taps, k of W2b[chan(f)][tap][k] * Ain[pixel(u) + tap][k]
         f32x4 acc1[4][2];
 #pragma unroll
@@ -140,45 +186,19 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
             const f32x4 bv = BK_BIAS(0, f);
             acc1[f][0] = bv; acc1[f][1] = bv;
         }
-        // tap by tap: the 4 fragment loads of tap t + 1 are issued before the 16 MFMAs of tap t (two register sets; the
-        // scheduling fences keep hipcc from hoisting all 36 loads of the strip to the top, which spilled 490 registers)
-#define BK_LOAD_TAP(T, DST)                                                                          \
-    {                                                                                                \
-        const int delta_ = (((T) / 3 - 1) * p.W + ((T) % 3 - 1)) * 128;                              \
-        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
-            const unsigned off_ = ((okmask[u_] >> (T)) & 1u) ? pbase[u_] + (unsigned)delta_ : BK_OOB; \
-            _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                    \
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off_, ks_ * 64, 0); \
-                DST[ks_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                   \
-            }                                                                                        \
-        }                                                                                            \
-    }
-#define BK_MUL_TAP(T, SRC)                                                                           \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                              \
-        _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                           \
-            const uint4 wf_ = BK_WFRAG(W2B_OFF + (T) * IMG, f_, ks_);                                \
-            BK_MFMA(acc1[f_][0], wf_, SRC[ks_][0]);                                                  \
-            BK_MFMA(acc1[f_][1], wf_, SRC[ks_][1]);                                                  \
-        }
         {
-            uint4 xa[2][2], xb[2][2];      // [k half][u], ping-pong
-            BK_LOAD_TAP(0, xa)
-#pragma unroll
-            for (int tp = 0; tp < 9; tp += 2) {
-                if (tp + 1 < 9) BK_LOAD_TAP(tp + 1, xb)
-                __builtin_amdgcn_sched_barrier(0);
-                BK_MUL_TAP(tp, xa)
-                __builtin_amdgcn_sched_barrier(0);
-                if (tp + 1 < 9) {
-                    if (tp + 2 < 9) BK_LOAD_TAP(tp + 2, xa)
-                    __builtin_amdgcn_sched_barrier(0);
-                    BK_MUL_TAP(tp + 1, xb)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            uint4 row1[3][2][2];
+            BK_LOAD_ROW(1, gc, row1)
+            __builtin_amdgcn_sched_barrier(0);
+            BK_MUL_ROW(0, row0)
+            __builtin_amdgcn_sched_barrier(0);
+            BK_LOAD_ROW(2, gc, row0)
+            __builtin_amdgcn_sched_barrier(0);
+            BK_MUL_ROW(1, row1)
+            __builtin_amdgcn_sched_barrier(0);
+            BK_MUL_ROW(2, row0)
+            __builtin_amdgcn_sched_barrier(0);
         }
-#undef BK_MUL_TAP
-#undef BK_LOAD_TAP
         // ReLU + bf16: the B operand of G2, k half s = fragments 2 s and 2 s + 1
         uint4 h1[2][2];             // [s][u]
 #pragma unroll
@@ -196,19 +216,19 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
             const f32x4 bv = BK_BIAS(320, f);
             acc3[f][0] = bv; acc3[f][1] = bv;
         }
-        const unsigned xoff[2] = {live[0] ? (unsigned)(p0 + c) * 512u + (unsigned)q * 16u : BK_OOB,
-                                  live[1] ? (unsigned)(p0 + 16 + c) * 512u + (unsigned)q * 16u : BK_OOB};
-#define BK_LOAD_RES(G, DST)                                                                          \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
-        _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u_], (G) * 128 + s_ * 64, 0); \
-            DST[s_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                        \
-        }
-        uint4 resq[2][2][2];        // [parity][s][u]: shortcut, channels 64 g + 32 s + 8 q .. + 8 of pixel (u, c); chunk g + 1 in flight
-        BK_LOAD_RES(0, resq[0])
+        uint4 resq[2][2][2];        // [parity][s][u]: shortcut, channels 64 g + 32 s + 8 q .. + 8 of pixel (u, c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) resq[0][s][u] = res0[s][u];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) BK_LOAD_RES(g + 1, resq[(g + 1) & 1])
+            if (g == 2) {           // the next strip's first loads go out ahead of this strip's last stores
+                geometry(strip + stride, gn);
+                BK_LOAD_ROW(0, gn, row0)
+                BK_LOAD_RES(0, gn, res0)
+            }
+            if (g + 1 < 4) BK_LOAD_RES(g + 1, gc, resq[(g + 1) & 1])
             __builtin_amdgcn_sched_barrier(0);
             uint4 (&res)[2][2] = resq[g & 1];
             f32x4 acc2[4][2];
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
                                                pack2(relu(hi[2] + bf_lo(r.w)), relu(hi[3] + bf_hi(r.w))));
                     xo[s][u] = o;
                     const u32x4 ov = {o.x, o.y, o.z, o.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)xoff[u], g * 128 + s * 64, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)((p.dbg & 4) ? BK_OOB : gc.xoff[u]), g * 128 + s * 64, 0);
                 }
             if (TAIL) {
 #pragma unroll
@@ -252,7 +272,6 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#undef BK_LOAD_RES
         if (TAIL) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -261,14 +280,27 @@ __global__ __launch_bounds__(BK_THREADS, 2) void bottleneck64_kernel(const BkPar
                     const f32x4 lo = acc3[2 * s][u], hi = acc3[2 * s + 1][u];
                     const u32x4 ov = {pack2(relu(lo[0]), relu(lo[1])), pack2(relu(lo[2]), relu(lo[3])),
                                       pack2(relu(hi[0]), relu(hi[1])), pack2(relu(hi[2]), relu(hi[3]))};
-                    const unsigned off = live[u] ? (unsigned)(p0 + 16 * u + c) * 128u + (unsigned)q * 16u : BK_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, n_rsrc, (int)off, s * 64, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, n_rsrc, (int)gc.aoff[u], s * 64, 0);
                 }
         }
+        gc = gn;
     }
+#undef BK_LOAD_RES
+#undef BK_MUL_ROW
+#undef BK_LOAD_ROW
 #undef BK_MFMA
 #undef BK_BIAS
 #undef BK_WFRAG
+}
+
+int rtn_bneck_threads() {
+    const char* e = getenv("RTN_BNECK_THREADS");
+    return (e && atoi(e) == 768) ? 768 : 512;       // 220 VGPRs with the cross-strip prefetch: two waves per SIMD
+}
+bool rtn_bneck_rowpp(int nt) {                           // two kernel rows of taps in flight (191 VGPRs) or one (fits 3 waves / SIMD)
+    const char* e = getenv("RTN_BNECK_ROWPP");
+    if (e && *e) return atoi(e) != 0;
+    return nt == 512;
 }
 
 }  // namespace
@@ -299,20 +331,31 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     p.nstrips = (int)((M + 31) / 32);
     p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
     p.inv_w = 1.0f / (float)d->W;
+    { const char* e = getenv("RTN_BNECK_DBG"); p.dbg = (e && *e) ? atoi(e) : 0; }
+    { const char* e = getenv("RTN_BNECK_PHASE"); p.phase_sleep = (e && *e) ? atoi(e) : 64; }
+    // 12 waves per CU (154 VGPRs: three per SIMD) keep 1.5 x the loads of 8 in flight; RTN_BNECK_THREADS=512 for the A/B
+    const int nt = rtn_bneck_threads();
     int grid = h->num_cus > 0 ? h->num_cus : 256;
-    const int wgs_needed = (p.nstrips + 7) / 8;
+    const int wgs_needed = (p.nstrips + nt / 64 - 1) / (nt / 64);
     if (grid > wgs_needed) grid = wgs_needed;
-#define RTN_BK_LAUNCH(T)                                                                                 \
+#define RTN_BK_LAUNCH(T, NTH, RP)                                                                        \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T>,                          \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, NTH, RP>,                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((bottleneck64_kernel<T>), dim3((unsigned)grid), dim3(BK_THREADS), BK_LDS, h->stream, p); \
+        hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
     } while (0)
-    if (tail) RTN_BK_LAUNCH(true); else RTN_BK_LAUNCH(false);
+    const bool rowpp = rtn_bneck_rowpp(nt);
+    if (nt == 768) {
+        if (rowpp) { if (tail) RTN_BK_LAUNCH(true, 768, true); else RTN_BK_LAUNCH(false, 768, true); }
+        else       { if (tail) RTN_BK_LAUNCH(true, 768, false); else RTN_BK_LAUNCH(false, 768, false); }
+    } else {
+        if (rowpp) { if (tail) RTN_BK_LAUNCH(true, 512, true); else RTN_BK_LAUNCH(false, 512, true); }
+        else       { if (tail) RTN_BK_LAUNCH(true, 512, false); else RTN_BK_LAUNCH(false, 512, false); }
+    }
 #undef RTN_BK_LAUNCH
     RTN_CHECK_LAUNCH(h, "bottleneck64_kernel");
     return RTN_OK;
