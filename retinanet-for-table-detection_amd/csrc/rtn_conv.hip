@@ -1428,7 +1428,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         const int h8 = rtn_env_int("RTN_CONV_H8", 1);
         const int forced = rtn_conv_impl_override();
         if (forced == 4 || (forced == 0 && h8 != 0)) {
-            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4);
+            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4, rtn_env_int("RTN_CONV_H8_MI", 0));
             if (rc == RTN_OK) h->last_conv_impl = 4;
             if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
         }

@@ -37,7 +37,6 @@ constexpr unsigned OOB = 0xFFFFFF00u;                 // beyond every descriptor
 constexpr int H8_THREADS = 512;
 constexpr int H8_LDS = 160 * 1024;
 constexpr unsigned B_STAGE = 32768, A_BASE = 3 * 32768, A_TOGGLE = 0x18000u ^ 0x20000u;
-constexpr unsigned ZERO_ROW = 255u * 128u;
 
 struct H8Group {
     const char* in;
@@ -90,15 +89,19 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KW, bool STAGGER>
+// MI = row fragments (16 rows) per wave: tiles of R = 64 MI rows (256 or 192).  The host picks the height that needs the fewest
+// rounds of workgroups x rows (P3 at batch 8: 529 tiles of 256 rows = 3 rounds, 707 tiles of 192 rows = 3 shorter rounds).
+template <int KW, int MI, bool STAGGER>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
-    constexpr int TM = 256 - KW;                       // output rows per tile; halo rows 0 .. 254, row 255 = zeros
+    constexpr int R = 64 * MI;                         // rows of a tile's halo image
+    constexpr int TM = R - KW;                         // output rows per tile; halo rows 0 .. R - 2, row R - 1 = zeros
+    constexpr unsigned ZERO_ROW = (unsigned)(R - 1) * 128u;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int grp = wave >> 2;                         // SIMD partners (w, w + 4) sit in different groups
-    const int wm = wave >> 1, wn = wave & 1;           // wave tile: rows [64 wm, +64) x columns [128 wn, +128)
+    const int wm = wave >> 1, wn = wave & 1;           // wave tile: rows [16 MI wm, + 16 MI) x columns [128 wn, +128)
     const int lr = lane >> 3, sc = (lane & 7) ^ lr;    // staging: row inside an 8-row piece, SOURCE chunk (swizzle on the source)
     const int lrow = lane & 15, kq = lane >> 4;        // fragment row / k quarter of this lane
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -122,14 +125,14 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     // ---- per-tile state ------------------------------------------------------------------------------------------------
     // staging cursor (the tile whose halos are being staged): its group, first row, halo rows of this lane
 
-    unsigned hbase[4];
-    int hiy[4];
+    unsigned hbase[MI];
+    int hiy[MI];
     i32x4 in_srd = w_srd;
     int st_Hin = 1, st_row_b = 0;
     auto stage_tile = [&](int T) {                     // T uniform; T >= ntiles: nothing to stage (zeros)
         if (T >= p.ntiles) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { hiy[i] = -(1 << 28); hbase[i] = 0; }
+            for (int i = 0; i < MI; ++i) { hiy[i] = -(1 << 28); hbase[i] = 0; }
             return;
         }
         int gi = 0;
@@ -144,10 +147,10 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         st_Hin = Gs.Hin;
         st_row_b = Gs.in_row_stride_b;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int h = (i * 8 + wave) * 8 + lr;
             const int f = m0 + h - p.pad_l;
-            if (h < 255 && f >= 0 && f < Gs.M) {
+            if (h < R - 1 && f >= 0 && f < Gs.M) {
                 int b, rem, y, x;
                 divmod24(f, cells, Gs.inv_cells, b, rem);
                 divmod24(rem, Gs.Win, Gs.inv_w, y, x);
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     // compute tile: A fragment read offsets per tap (k half 0; half 1 = ^ 64), the zero row where the tap leaves the image.
     // a_cur = LDS offset of the halo buffer the current group reads (toggles per group, also across tiles)
     unsigned a_cur = A_BASE;
-    unsigned arow[KW][4];
+    unsigned arow[KW][MI];
     auto compute_tile = [&](int T, int& gi_out, int& m0_out) {
         int gi = 0;
 #pragma unroll
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         gi_out = gi;
         m0_out = m0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rloc = wm * 64 + i * 16 + lrow;
+        for (int i = 0; i < MI; ++i) {
+            const int rloc = wm * (16 * MI) + i * 16 + lrow;
             const int m = m0 + rloc;
             const int mc = m < Gc.M ? m : Gc.M - 1;
             int b, rem, y, x;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[MI][8];
     float bias8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     int tile = blockIdx.x;
     stage_tile(tile);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stage_a(i, 0, 0, A_BASE);
+    for (int i = 0; i < MI; ++i) stage_a(i, 0, 0, A_BASE);
 #pragma unroll
     for (int d = 0; d < 4; ++d) stage_b(d, 0u, 0);
 #pragma unroll
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 
 
 #define H8_LDA(KWI, KS)                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                                \
         fa[i_] = *reinterpret_cast<const uint4*>(lds + (arow[KWI][i_] ^ ((KS) * 64u)));
 #define H8_LDB(KWI, KS, HALF)                                                                        \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
             acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
                 __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                   \
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     {                                                                                                \
         const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
         const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
-        uint4 fa[4], fb[4];                                                                          \
+        uint4 fa[MI], fb[4];                                                                         \
         /* phase 1 */                                                                                \
         H8_LDA(KWI, 0) H8_LDB(KWI, 0, 0)                                                             \
         stage_b(3, kc_n1, ((KWI) + 1) % 3);                                                          \
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         /* phase 2 */                                                                                \
         H8_LDB(KWI, 0, 1)                                                                            \
         stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
-        if ((KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);                                   \
+        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);                 \
         H8_MFMA(1)                                                                                   \
         /* phase 3 */                                                                                \
         H8_LDA(KWI, 1) H8_LDB(KWI, 1, 0)                                                             \
@@ -268,19 +271,24 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         /* phase 4 */                                                                                \
         H8_LDB(KWI, 1, 1)                                                                            \
         stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
-        if ((KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);                               \
-        if ((KWI) < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                              \
-        else           asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                              \
+        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);         \
+        /* B(s+1) must have landed: allowed in flight = what this step issued after its phase 1 (3 B pieces + its halo pieces) */ \
+        {                                                                                            \
+            constexpr int na_ = (KWI) < 2 ? ((2 * (KWI) < MI) + (2 * (KWI) + 1 < MI)) : 0;           \
+            if (na_ == 2)      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                      \
+            else if (na_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+            else               asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
+        }                                                                                            \
         H8_MFMA(1)                                                                                   \
     }
-    static_assert(KW == 3, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3");
+    static_assert(KW == 3 && MI >= 2 && MI <= 4, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3, MI <= 4");
 
     const unsigned kw_stride = (unsigned)(nchunk * 128);           // K bytes between the taps of a kernel row
     while (tile < p.ntiles) {
         int gi, m0;
         compute_tile(tile, gi, m0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
         int kh = 0, cc = 0;
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) arow[kw][i] ^= A_TOGGLE;
+                for (int i = 0; i < MI; ++i) arow[kw][i] ^= A_TOGGLE;
             a_cur ^= A_TOGGLE;
             kh = kh1; cc = cc1;
         }
@@ -314,10 +322,10 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             const int ncol = wn * 128 + 8 * lrow;
             const bool col_ok = ncol < p.N;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int rloc = wm * 64 + i * 16 + kq * 4 + r;
+                    const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
                     const int m = m0 + rloc;
                     float v[8];
 #pragma unroll
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 
 // Launcher.  Returns RTN_OK after a launch, 1 when the layer is not one this kernel takes (the caller falls through to the other
 // kernels), < 0 on a launch error.  `force`: take every eligible layer (tests), otherwise the caller decides.
-int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced) {
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force) {
     if (d->dtype != RTN_BF16) return 1;
     if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
     if (d->flags & ~RTN_CONV_RELU) return 1;
@@ -359,9 +367,21 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     const int nchunk = d->Crun * 2 / 128;
     const long long Kbytes = (long long)d->KH * d->KW * d->Crun * 2;
     if (Kbytes * 256 >= 0xFFFFFF00ll) return 1;
-    constexpr int TM = 256 - 3;
     H8Params p;
     memset(&p, 0, sizeof(p));
+    const int cus = h->num_cus > 0 ? h->num_cus : 256;
+    // tile height: rounds of workgroups x (rows + a fixed per-tile cost); RTN_CONV_H8_MI pins it (A/B, tests)
+    int mi = mi_force;
+    if (mi < 3 || mi > 4) {
+        double best = 0;
+        for (int cand = 4; cand >= 3; --cand) {
+            long long t = 0;
+            for (int i = 0; i < d->ngroups; ++i) t += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 64 * cand - 4) / (64 * cand - 3);
+            const double cost = (double)((t + cus - 1) / cus) * (cand + 0.3);
+            if (cand == 4 || cost < best * 0.97) { best = cost; mi = cand; }
+        }
+    }
+    const int TM = 64 * mi - 3;
     long long tiles = 0;
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
@@ -389,7 +409,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     // one 256 x 256 tile per CU: below a quarter of the chip the narrow tiles of generation 2 (four times the workgroups) are
     // faster (P5 at batch 8: 34 tiles, 0.049 ms here against 0.037 ms); from half the chip on this kernel wins (res4 3x3, P4:
     // 133 tiles, 0.054 against 0.067 ms)
-    if (!forced && tiles * 4 < (h->num_cus > 0 ? h->num_cus : 256)) return 1;
+    if (!forced && tiles * 4 < cus) return 1;
     p.w = (const char*)d->w;
     p.bias = d->bias;
     p.w_bytes = (unsigned)(Kbytes * 256);
@@ -403,20 +423,21 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
     p.out_ld = d->out_ld;
     p.pix_b = d->pix_stride * 2;
-    int grid = h->num_cus > 0 ? h->num_cus : 256;
+    int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;
-#define RTN_H8_LAUNCH(ST)                                                                                \
+#define RTN_H8_LAUNCH(M_, ST)                                                                            \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, ST>,                        \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST>,                    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, ST>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
-    if (stagger) RTN_H8_LAUNCH(true); else RTN_H8_LAUNCH(false);
+    if (mi == 4) { if (stagger) RTN_H8_LAUNCH(4, true); else RTN_H8_LAUNCH(4, false); }
+    else         { if (stagger) RTN_H8_LAUNCH(3, true); else RTN_H8_LAUNCH(3, false); }
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
     return RTN_OK;

@@ -42,7 +42,7 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 
 // rtn_conv_halo8.hip: persistent 8-phase kernel for the stride-1 3x3 layers with 129..256 output channels (head towers, P3-P5,
 // res4 branch2b).  RTN_OK = launched, 1 = not a layer this kernel takes, < 0 = error.
-int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced);
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force);
 
 static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }
 

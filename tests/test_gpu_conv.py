@@ -230,7 +230,7 @@ def test_tail_split(pkg, handle, monkeypatch, dtype, impl, levels, cin, cout, k,
         assert not torch.equal(a, b) or dtype == "bf16"      # f32: the split changes the summation order somewhere
 
 
-@pytest.mark.parametrize("stagger", [1, 0])
+@pytest.mark.parametrize("stagger,mi", [(1, 4), (0, 4), (1, 3), (0, 3)])
 @pytest.mark.parametrize("levels,cin,cout,relu,B,grid", [
     ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, True, 2, 0),      # head-tower shape: five levels, one grouped launch
     ([(40, 67)], 256, 256, False, 3, 3),       # P3-like, no ReLU; 32 tiles on 3 workgroups: every workgroup walks ~11 tiles
@@ -238,7 +238,7 @@ def test_tail_split(pkg, handle, monkeypatch, dtype, impl, levels, cin, cout, k,
     ([(7, 300)], 256, 136, True, 1, 2),        # rows longer than a tile: tiles start and end inside an image row
     ([(3, 5)], 256, 256, True, 1, 0),          # a single, mostly empty tile
 ])
-def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, relu, B, grid, stagger):
+def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, relu, B, grid, stagger, mi):
     """Generation 4 (csrc/rtn_conv_halo8.hip): persistent 256 x 256 tiles on the staggered 8-phase schedule, LDS-DMA in flight
     across barriers behind counted waits, weight rows permuted for a register epilogue.  RTN_CONV_IMPL=4 takes it wherever it
     applies, RTN_CONV_H8_GRID limits the workgroup count so that workgroups walk several tiles (the halo / B-ring prefetch then
@@ -248,6 +248,7 @@ def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, co
     monkeypatch.setenv("RTN_CONV_IMPL", "4")
     monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
     monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(stagger))
+    monkeypatch.setenv("RTN_CONV_H8_MI", str(mi))            # tile height 64 * mi rows (256 / 192)
     flags = L.CONV_RELU if relu else 0
     gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, None, B=B, seed=90 + grid)
     assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
@@ -269,6 +270,7 @@ def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     first = None
     for it in range(12):
         monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(1 - it % 2))
+        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 8 else "3")
         gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
                                       reference=(it == 0))
         assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
@@ -276,7 +278,7 @@ def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
             check(gots, wants, ld, n, "bf16")
             first = gots
         else:
-            for a, b in zip(gots, first):
+            for a, b in zip(gots, first):           # the tile height does not change a pixel's summation order either
                 assert torch.equal(a, b), "launch %d differs" % it
 
 
