@@ -1,0 +1,400 @@
+// rtn_conv_gemm8.hip — the 1x1 convolutions with >= 256 output channels as a PERSISTENT implicit GEMM on the staggered 8-phase
+// schedule of rtn_conv_halo8.hip (cdna_hip_programming.md §5): fifth kernel generation.
+//
+// Replaces conv_igemm2_kernel (rtn_conv.hip) on the keras_resnet bottleneck 1x1 layers behind model/defineModel.py:376-380 and the
+// FPN laterals (model/defineModel.py:183-195) that have a bias / ReLU epilogue:
+//   res{3,4,5}*_branch2a (also the stride-2 'valid' form of a stage's first block), the first blocks' branch2c with the projection
+//   shortcut appended along K (rtn_conv1x1_dual_fwd), C5_reduced.
+// Those layers are short GEMMs (M = 8,400 .. 133,600 rows at batch 8, K = 128 .. 2048): with one workgroup per 256 x 64 tile the
+// per-workgroup prologue (first LDS-DMA round trip), the epilogue and the launch ramp cost more than the K loop.  Here a workgroup
+// walks its tiles as ONE stream of K steps, exactly like generation 4:
+//   * tile = 64 MI rows (192 or 128) x 256 columns, 8 waves as 4 (M) x 2 (N), wave tile 16 MI x 128, K step 64 = 4 phases of
+//     {fragment reads + LDS-DMA issue | s_barrier | 4 MI MFMAs | s_barrier}; waves 4-7 run one barrier behind waves 0-3;
+//   * A (activation) tiles in a ring of 3, B (weight) tiles in a ring of 2.  vmcnt retires in order, so the operand that needs the
+//     long prefetch is issued LAST in every step: B(s+1) goes out in phases 2-3 (weights are L2-resident: two phases cover them),
+//     A(s+2) in phases 3-4 (HBM: it gets two whole steps), and the step's one counted wait, vmcnt(MI), leaves exactly the A pieces
+//     in flight.  A buffer is restaged >= 2 phases after its last read and read one phase after the wait that retires it;
+//   * the K loop walks two sources back to back (K-concatenated projection shortcut) and either source may be sampled with a
+//     stride (the stride-2 1x1 'valid' convolutions): both are per-row byte offsets computed once per tile;
+//   * weight rows permuted at staging (position 16 j + c <-> channel 8 c + j): bias-initialised accumulators, ReLU, bf16 and
+//     16-byte stores straight from registers, as in generation 4; the bias vector sits in the unused tail of the first A stage.
+// LDS: A ring 3 x 32 KiB (24 KiB used, bias in the tail of stage 0), B ring 2 x 32 KiB = 160 KiB.  One workgroup per CU.
+#include "rtn_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr unsigned G8_OOB = 0xFFFF0000u;              // beyond every descriptor even with the largest uniform offset (K bytes) added
+constexpr int G8_THREADS = 512;
+constexpr int G8_LDS = 160 * 1024;
+constexpr unsigned G8_STAGE = 32768, G8_B_BASE = 3 * 32768, G8_BIAS_OFF = 24576;
+
+struct G8Src {
+    const char* ptr;
+    unsigned bytes;
+    long long img_stride_b;       // bytes between images
+    int row_stride_b, pix_b;      // bytes between rows / pixels
+    int step;                     // output pixel (oy, ox) reads input pixel (oy * step, ox * step)
+};
+
+struct G8Params {
+    G8Src s1, s2;                 // s2.ptr == nullptr: single source
+    const char* w;
+    const float* bias;
+    char* out;
+    unsigned w_bytes, out_bytes;
+    int M, N, Kbytes, nk, nk1;    // K steps in all / from the first source
+    int ntiles_m, ntiles_n, ntiles;
+    int Hout, Wout;
+    float inv_cells, inv_w;
+    int relu, out_ld;
+};
+
+__device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void dma16(const i32x4& srd, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(srd), "s"(soff)
+                 : "memory");
+}
+
+__device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r) {
+    q = (int)((float)f * inv);
+    r = f - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int MI, bool STAGGER, bool DUAL>
+__global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Params p) {
+    constexpr int R = 64 * MI;                         // rows of a tile
+    static_assert(MI >= 2 && MI <= 3, "the bias table lives in the tail of A stage 0: tiles of at most 192 rows");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane >> 3, sc = (lane & 7) ^ lr;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int nk = p.nk;
+    const i32x4 w_srd = make_srd(p.w, p.w_bytes);
+    const i32x4 s1_srd = make_srd(p.s1.ptr, p.s1.bytes);
+    const i32x4 s2_srd = DUAL ? make_srd(p.s2.ptr, p.s2.bytes) : s1_srd;
+
+    // bias -> LDS (unused tail of A stage 0), once
+    {
+        float* bl = reinterpret_cast<float*>(lds + G8_BIAS_OFF);
+        for (int i = t; i < p.N; i += G8_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
+    }
+
+    // workgroup -> first tile: tiles that share an A row block (same m tile) are neighbours; workgroups b and b + 8 share an XCD
+    int tile;
+    {
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tstride = (int)gridDim.x;
+
+    // ---- staging cursors.  A: per-row byte offsets of this lane's MI rows in both sources (out of range past M);
+    //      B: per-piece byte offsets of the weight rows of the tile's 256 columns (permuted, see the header)
+    unsigned hoff1[MI], hoff2[DUAL ? MI : 1];
+    auto a_tile = [&](int T) {
+        const int mt = T / p.ntiles_n;
+        const int m0 = mt * R;
+        const int cells = p.Hout * p.Wout;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + (i * 8 + wave) * 8 + lr;
+            if (T < p.ntiles && m < p.M) {
+                int b, rem, oy, ox;
+                divmod24(m, cells, p.inv_cells, b, rem);
+                divmod24(rem, p.Wout, p.inv_w, oy, ox);
+                hoff1[i] = (unsigned)((long long)b * p.s1.img_stride_b + (long long)(oy * p.s1.step) * p.s1.row_stride_b +
+                                      (long long)(ox * p.s1.step) * p.s1.pix_b) + (unsigned)sc * 16u;
+                if (DUAL)
+                    hoff2[i] = (unsigned)((long long)b * p.s2.img_stride_b + (long long)(oy * p.s2.step) * p.s2.row_stride_b +
+                                          (long long)(ox * p.s2.step) * p.s2.pix_b) + (unsigned)sc * 16u;
+            } else {
+                hoff1[i] = G8_OOB;
+                if (DUAL) hoff2[i] = G8_OOB;
+            }
+        }
+    };
+    unsigned wrow_off[4];
+    auto b_tile = [&](int T) {
+        const int nt = T < p.ntiles ? T - (T / p.ntiles_n) * p.ntiles_n : 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int P = d * 64 + wave * 8 + lr;
+            const int nrow = nt * 256 + (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7);
+            wrow_off[d] = (unsigned)nrow * (unsigned)p.Kbytes + (unsigned)sc * 16u;
+        }
+    };
+    auto stage_a = [&](int i, int k, unsigned slot_addr) {          // piece i of the A tile of K step k of the A cursor's tile
+        if (DUAL && k >= p.nk1) dma16(s2_srd, hoff2[DUAL ? i : 0], (unsigned)(k - p.nk1) * 128u, lds_base + slot_addr + (unsigned)(wave * 1024 + i * 8192));
+        else                    dma16(s1_srd, hoff1[i], (unsigned)k * 128u, lds_base + slot_addr + (unsigned)(wave * 1024 + i * 8192));
+    };
+    auto stage_b = [&](int d, int k, unsigned slot_addr) {
+        dma16(w_srd, wrow_off[d], (unsigned)k * 128u, lds_base + slot_addr + (unsigned)(wave * 1024 + d * 8192));
+    };
+
+    // fragment read offsets (fixed for the whole kernel): A row 16 MI wm + 16 i + lrow, B position 128 wn + 16 j + lrow
+    unsigned arow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * (16 * MI) + i * 16 + lrow;
+        arow[i] = (unsigned)(row * 128 + ((kq ^ (row & 7)) << 4));
+    }
+    const unsigned b_lane = G8_B_BASE + (unsigned)((wn * 128 + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
+
+    // ---- prologue: A tiles of steps 0 and 1, B tile of step 0
+    int ta = tile, ka = 0;          // A cursor: the step whose A tile is staged next (two ahead of the multiply)
+    int tb = tile, kb = 0;          // B cursor (one ahead)
+    a_tile(ta);
+    b_tile(tb);
+    unsigned a_st = 0, b_st = 0;    // ring slots the cursors stage into next (byte offsets)
+#define G8_ADV_A()                                                                                   \
+    {                                                                                                \
+        a_st = a_st == 2 * G8_STAGE ? 0u : a_st + G8_STAGE;                                          \
+        if (++ka == nk) { ka = 0; ta += tstride; a_tile(ta); }                                       \
+    }
+#define G8_ADV_B()                                                                                   \
+    {                                                                                                \
+        b_st ^= G8_STAGE;                                                                            \
+        if (++kb == nk) { kb = 0; tb += tstride; b_tile(tb); }                                       \
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) stage_a(i, ka, a_st);
+        G8_ADV_A()
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) stage_b(d, kb, G8_B_BASE + b_st);
+    G8_ADV_B()
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the LDS-DMA pieces and this wave's bias stores
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                      // also publishes the bias table
+
+    unsigned a_cur = 0, b_cur = 0;                     // ring slots of the step being multiplied
+    f32x4 acc[MI][8];
+    const float* bias_l = reinterpret_cast<const float*>(lds + G8_BIAS_OFF);
+
+#define G8_LDA(KS)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                                \
+        fa[i_] = *reinterpret_cast<const uint4*>(lds + a_cur + (arow[i_] ^ ((KS) * 64u)));
+#define G8_LDB(KS, HALF)                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+        fb[j_] = *reinterpret_cast<const uint4*>(lds + b_cur + (b_lane ^ ((KS) * 64u)) + ((HALF) * 4 + j_) * 2048);
+#define G8_MFMA(HALF)                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
+            acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+                __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_barrier();
+
+    while (tile < p.ntiles) {
+        const int mt = tile / p.ntiles_n, nt = tile - mt * p.ntiles_n;
+        const int m0 = mt * R, n0 = nt * 256;
+        {
+            const float* bp = bias_l + n0 + wn * 128 + 8 * lrow;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = (f32x4){b0[j], b0[j], b0[j], b0[j]};
+                    acc[i][4 + j] = (f32x4){b1[j], b1[j], b1[j], b1[j]};
+                }
+            }
+        }
+#pragma unroll 1
+        for (int k = 0; k < nk; ++k) {
+            uint4 fa[MI], fb[4];
+            // phase 1: no staging (the B stage freed by step k-1 may still be read by the lagging wave group)
+            G8_LDA(0) G8_LDB(0, 0)
+            G8_MFMA(0)
+            // phase 2: first half of B(s+1)
+            G8_LDB(0, 1)
+            stage_b(0, kb, G8_B_BASE + b_st);
+            stage_b(1, kb, G8_B_BASE + b_st);
+            G8_MFMA(1)
+            // phase 3: second half of B(s+1), first piece of A(s+2)
+            G8_LDA(1) G8_LDB(1, 0)
+            stage_b(2, kb, G8_B_BASE + b_st);
+            stage_b(3, kb, G8_B_BASE + b_st);
+            G8_ADV_B()
+            stage_a(0, ka, a_st);
+            G8_MFMA(0)
+            // phase 4: the rest of A(s+2); everything but those MI pieces must have landed (B(s+1), and A(s+1) from the step before)
+            G8_LDB(1, 1)
+#pragma unroll
+            for (int i = 1; i < MI; ++i) stage_a(i, ka, a_st);
+            G8_ADV_A()
+            if (MI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            G8_MFMA(1)
+            a_cur = a_cur == 2 * G8_STAGE ? 0u : a_cur + G8_STAGE;
+            b_cur ^= G8_STAGE;
+        }
+        // ---- epilogue: ReLU, bf16, 4 MI stores of 16 B per lane
+        {
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)p.out, 0, (int)__builtin_amdgcn_readfirstlane((int)p.out_bytes), 0x00020000);
+            const int ncol = n0 + wn * 128 + 8 * lrow;
+            const bool col_ok = ncol < p.N;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = acc[i][j][r];
+                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                    u32x4 o;
+                    o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+                    const unsigned off = (col_ok && m < p.M) ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : G8_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
+                }
+        }
+        tile += tstride;
+    }
+#undef G8_MFMA
+#undef G8_LDB
+#undef G8_LDA
+#undef G8_ADV_B
+#undef G8_ADV_A
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace
+
+// Launcher: RTN_OK after a launch, 1 when the layer is not one this kernel takes, < 0 on error.
+int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2, int grid_limit, bool stagger, bool forced,
+                       int mi_force) {
+    if (d->dtype != RTN_BF16 || d->ngroups != 1) return 1;
+    if (d->KH != 1 || d->KW != 1 || d->pad_t != 0 || d->pad_l != 0 || d->sy != d->sx || d->sy < 1 || d->sy > 2) return 1;
+    if (d->flags & ~RTN_CONV_RELU) return 1;
+    if (d->N < 256 || d->N % 256 || d->N > 2048 || d->w_rows != d->N || d->out_ld % 8) return 1;
+    if ((d->Crun * 2) % 128 || d->Crun <= 0 || d->pix_stride < d->Crun || (d->pix_stride * 2) % 16) return 1;
+    if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
+    const rtn_conv_group_t& g = d->g[0];
+    if (!g.in || !g.out || ((uintptr_t)g.in & 15) || ((uintptr_t)g.out & 15)) return 1;
+    const long long cells = (long long)g.Hout * g.Wout, M = cells * d->batch;
+    if (M < 1 || M >= (1ll << 24)) return 1;
+    if (g.out_step > 1 || g.out_off != 0 || g.out_img_stride != cells * d->out_ld) return 1;
+    if ((long long)(g.Hout - 1) * d->sy >= g.Hin || (long long)(g.Wout - 1) * d->sx >= g.Win) return 1;
+    if (g.in_elems * 2 >= (long long)G8_OOB || g.out_elems * 2 >= (long long)G8_OOB) return 1;
+    if (g.out_elems < (M - 1) * d->out_ld + d->N) return 1;
+    const long long in_max = (long long)(d->batch - 1) * g.in_img_stride + (long long)(g.Hout - 1) * d->sy * g.in_row_stride +
+                             (long long)(g.Wout - 1) * d->sx * d->pix_stride + d->Crun;
+    if (in_max > g.in_elems) return 1;
+    long long Kel = d->Crun;
+    G8Params p;
+    memset(&p, 0, sizeof(p));
+    p.s1.ptr = (const char*)g.in;
+    p.s1.bytes = (unsigned)(g.in_elems * 2);
+    p.s1.img_stride_b = g.in_img_stride * 2;
+    p.s1.row_stride_b = (int)((long long)g.in_row_stride * 2);
+    p.s1.pix_b = d->pix_stride * 2;
+    p.s1.step = d->sy;
+    p.nk1 = d->Crun * 2 / 128;
+    if (s2) {
+        if (!s2->in || ((uintptr_t)s2->in & 15) || s2->C < 1 || (s2->C * 2) % 128 || s2->step < 1) return 1;
+        if ((long long)(g.Hout - 1) * s2->step >= s2->Hin || (long long)(g.Wout - 1) * s2->step >= s2->Win) return 1;
+        const long long in2_max = (long long)(d->batch - 1) * s2->in_img_stride + (long long)(g.Hout - 1) * s2->step * s2->in_row_stride +
+                                  (long long)(g.Wout - 1) * s2->step * s2->pix_stride + s2->C;
+        if (in2_max > s2->in_elems || s2->in_elems * 2 >= (long long)G8_OOB) return 1;
+        p.s2.ptr = (const char*)s2->in;
+        p.s2.bytes = (unsigned)(s2->in_elems * 2);
+        p.s2.img_stride_b = s2->in_img_stride * 2;
+        p.s2.row_stride_b = (int)((long long)s2->in_row_stride * 2);
+        p.s2.pix_b = s2->pix_stride * 2;
+        p.s2.step = s2->step;
+        Kel += s2->C;
+    }
+    const long long Kbytes = Kel * 2;
+    if (Kbytes > 16384 || Kbytes * d->N >= (long long)G8_OOB) return 1;
+    const int cus = h->num_cus > 0 ? h->num_cus : 256;
+    const int ntn = d->N / 256;
+    int mi = mi_force;
+    if (mi < 2 || mi > 3) {                            // tile height by rounds x (rows + a fixed per-tile cost)
+        double best = 0;
+        for (int cand = 3; cand >= 2; --cand) {
+            const long long tl = ((M + 64 * cand - 1) / (64 * cand)) * ntn;
+            const double cost = (double)((tl + cus - 1) / cus) * (cand + 0.4);
+            if (cand == 3 || cost < best * 0.97) { best = cost; mi = cand; }
+        }
+    }
+    const long long ntm = (M + 64 * mi - 1) / (64 * mi), tiles = ntm * ntn;
+    if (tiles > 0x3fffffff) return 1;
+    if (!forced && tiles * 4 < cus) return 1;          // too few tiles to be worth one workgroup per CU
+    p.w = (const char*)d->w;
+    p.bias = d->bias;
+    p.out = (char*)g.out;
+    p.w_bytes = (unsigned)(Kbytes * d->N);
+    p.out_bytes = (unsigned)(g.out_elems * 2);
+    p.M = (int)M; p.N = d->N; p.Kbytes = (int)Kbytes; p.nk = (int)(Kbytes / 128);
+    p.ntiles_m = (int)ntm; p.ntiles_n = ntn; p.ntiles = (int)tiles;
+    p.Hout = g.Hout; p.Wout = g.Wout;
+    p.inv_cells = 1.0f / (float)cells;
+    p.inv_w = 1.0f / (float)g.Wout;
+    p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
+    p.out_ld = d->out_ld;
+    int grid = cus;
+    if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
+    if (grid > p.ntiles) grid = p.ntiles;
+#define RTN_G8_LAUNCH(M_, ST, DU)                                                                        \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, ST, DU>,                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_gemm8_kernel<M_, ST, DU>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
+    } while (0)
+#define RTN_G8_PICK(M_)                                                                                  \
+    do {                                                                                                 \
+        if (s2) { if (stagger) RTN_G8_LAUNCH(M_, true, true); else RTN_G8_LAUNCH(M_, false, true); }     \
+        else    { if (stagger) RTN_G8_LAUNCH(M_, true, false); else RTN_G8_LAUNCH(M_, false, false); }   \
+    } while (0)
+    if (mi == 3) RTN_G8_PICK(3); else RTN_G8_PICK(2);
+#undef RTN_G8_PICK
+#undef RTN_G8_LAUNCH
+    RTN_CHECK_LAUNCH(h, "conv_gemm8_kernel");
+    return RTN_OK;
+}

@@ -44,6 +44,11 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 // res4 branch2b).  RTN_OK = launched, 1 = not a layer this kernel takes, < 0 = error.
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force);
 
+// rtn_conv_gemm8.hip: the same schedule as a plain GEMM for the 1x1 layers with N % 256 == 0 and a bias / ReLU epilogue, one or
+// two (K-concatenated) sources, stride 1 or 2.
+int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2, int grid_limit, bool stagger, bool forced,
+                       int mi_force);
+
 static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }
 
 // bf16 helpers on raw bits (device + host)

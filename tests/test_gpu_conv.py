@@ -261,6 +261,35 @@ def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, co
         assert float((a - b).abs().max()) <= 4e-2 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("stagger", [1, 0])
+@pytest.mark.parametrize("levels,cin,cout,stride,relu,B,grid,mi", [
+    ([(25, 42)], 512, 256, 1, True, 8, 0, 0),      # res4 branch2a-like at batch 8: 8400 rows, 8 K steps, default grid and tile height
+    ([(33, 50)], 256, 512, 2, True, 2, 3, 3),      # stride-2 'valid' 1x1 of a stage's first block, two N tiles, 3 workgroups walk 4 tiles each
+    ([(17, 23)], 64, 256, 1, False, 3, 1, 2),      # ONE K step per tile: the rings turn over at every tile; one workgroup walks all tiles
+    ([(40, 67)], 1024, 1024, 1, True, 1, 0, 0),    # 16 K steps, four N tiles
+    ([(5, 7)], 128, 256, 1, True, 1, 0, 3),        # a single partly filled tile
+])
+def test_persistent_gemm8_kernel(pkg, handle, monkeypatch, levels, cin, cout, stride, relu, B, grid, mi, stagger):
+    """Generation 5 (csrc/rtn_conv_gemm8.hip): the 1x1 layers with N % 256 == 0 as a persistent GEMM on the staggered 8-phase schedule
+    (A ring of 3 issued last in every step, B ring of 2, counted waits, register epilogue).  RTN_CONV_IMPL=5 takes it wherever it
+    applies; the launch must really have been generation 5.  Against the float64 product of the bf16-rounded operands, and against
+    generation 2 on the same layer."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(stagger))
+    monkeypatch.setenv("RTN_CONV_G8_MI", str(mi))
+    flags = L.CONV_RELU if relu else 0
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 1, stride, 0, flags, None, B=B, seed=60 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+    check(gots, wants, ld, n, "bf16")
+    monkeypatch.setenv("RTN_CONV_IMPL", "2")
+    gots2, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 1, stride, 0, flags, None, B=B, seed=60 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 2
+    for a, b in zip(gots, gots2):
+        assert float((a - b).abs().max()) <= 4e-2 * max(1.0, float(b.abs().max()))
+
+
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
