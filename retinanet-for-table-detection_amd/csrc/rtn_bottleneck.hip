@@ -69,6 +69,20 @@ __device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
+// Store-data guard.  Observed on MI355X (ROCm 7.2): hipcc pads a 16-byte buffer store whose data registers are rewritten by the
+// next VALU instructions with the documented two wait states (s_nop 1); with the vector-memory front end backed up (this kernel
+// keeps the TA 73 % busy) the store had not yet read dword 0 of its last lanes, and the output came out corrupted in a few
+// hundred pixels per launch, differently every run.  The guard keeps the data registers live across RTN_BK_STORE_NOPS + 1 more wait
+// states (the asm statement names them as inputs), so nothing the compiler schedules can overwrite them earlier.
+#ifndef RTN_BK_STORE_NOPS
+#define RTN_BK_STORE_NOPS 3
+#endif
+#if RTN_BK_STORE_NOPS < 0
+#define BK_STORE_GUARD(V)
+#else
+#define BK_STORE_GUARD(V) asm volatile("s_nop %4" :: "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "n"(RTN_BK_STORE_NOPS));
+#endif
+
 template <bool TAIL, int BK_THREADS, bool ROWPP>
 __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_kernel(const BkParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
             for (int u = 0; u < 2; ++u) resq[0][s][u] = res0[s][u];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g == 2) {           // the next strip's first loads go out ahead of this strip's last stores
+            if (ROWPP && g == 2) {  // the next strip's first loads go out ahead of this strip's last stores
                 geometry(strip + stride, gn);
                 BK_LOAD_ROW(0, gn, row0)
                 BK_LOAD_RES(0, gn, res0)
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                     xo[s][u] = o;
                     const u32x4 ov = {o.x, o.y, o.z, o.w};
                     __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)((p.dbg & 4) ? BK_OOB : gc.xoff[u]), g * 128 + s * 64, 0);
+                    BK_STORE_GUARD(ov)
                 }
             if (TAIL) {
 #pragma unroll
@@ -281,7 +296,13 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                     const u32x4 ov = {pack2(relu(lo[0]), relu(lo[1])), pack2(relu(lo[2]), relu(lo[3])),
                                       pack2(relu(hi[0]), relu(hi[1])), pack2(relu(hi[2]), relu(hi[3]))};
                     __builtin_amdgcn_raw_buffer_store_b128(ov, n_rsrc, (int)gc.aoff[u], s * 64, 0);
+                    BK_STORE_GUARD(ov)
                 }
+        }
+        if (!ROWPP) {               // A/B: the unpipelined order (next strip's loads behind this strip's stores)
+            geometry(strip + stride, gn);
+            BK_LOAD_ROW(0, gn, row0)
+            BK_LOAD_RES(0, gn, res0)
         }
         gc = gn;
     }
@@ -297,10 +318,10 @@ int rtn_bneck_threads() {
     const char* e = getenv("RTN_BNECK_THREADS");
     return (e && atoi(e) == 768) ? 768 : 512;       // 220 VGPRs with the cross-strip prefetch: two waves per SIMD
 }
-bool rtn_bneck_rowpp(int nt) {                           // two kernel rows of taps in flight (191 VGPRs) or one (fits 3 waves / SIMD)
+bool rtn_bneck_rowpp(int nt) {                           // cross-strip software pipeline (RTN_BNECK_ROWPP=0: off, for the A/B)
     const char* e = getenv("RTN_BNECK_ROWPP");
     if (e && *e) return atoi(e) != 0;
-    return nt == 512;
+    return true;
 }
 
 }  // namespace

@@ -84,6 +84,12 @@ __device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r
     if (r >= d) { ++q; r -= d; }
 }
 
+// A 16-byte buffer store whose data registers the following VALU instructions rewrite: hipcc pads the documented two wait states,
+// which on MI355X (ROCm 7.2) is not enough when the vector-memory front end is backed up (found in rtn_bottleneck.hip: corrupted
+// dword 0 of the store's last lanes, a few hundred pixels per launch).  Naming the data registers as inputs of an asm statement
+// keeps them intact for four more wait states, whatever the compiler schedules next.
+#define RTN_STORE_GUARD(V) asm volatile("s_nop 3" :: "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w));
+
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     const bool ok = col_ok && rloc < TM && m < Gc.M;
                     const unsigned off = ok ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
+                    RTN_STORE_GUARD(o)
                 }
         }
         tile += (int)gridDim.x;

@@ -247,6 +247,41 @@ def test_full_size_passes_repeat_bit_for_bit(pkg, state):
 
 
 @pytest.mark.gpu
+def test_full_size_backbone_outputs_repeat_and_match_the_unfused_path(pkg, state):
+    """The fused bottleneck blocks (rtn_bottleneck64_fwd) and the persistent kernels at the BASELINE size: six forward passes must
+    give identical C2..C5 bits (a store-data hazard in the fused kernel once corrupted a few hundred pixels per launch, differently
+    every run - see the guard in csrc/rtn_bottleneck.hip), and the fused path must agree with the same engine running every
+    bottleneck layer as its own launch to 2^-6 of each feature map's scale (same bf16 rounding points, other f32 summation order)."""
+    E, _ = mods(pkg)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(8, 800, 1333, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.load_state(state)
+    feats = {}
+    for fuse in (True, False):
+        eng.fuse_bottleneck = fuse
+        plan = eng._plan(8, 800, 1333)
+        first = None
+        for rep in range(6 if fuse else 1):
+            for t in plan["feats"]:
+                t.fill_(-7.0)
+            eng.forward(x)
+            torch.cuda.synchronize()
+            cur = [t.clone() for t in plan["feats"]]
+            if first is None:
+                first = cur
+            else:
+                for lvl, (a, b) in enumerate(zip(first, cur)):
+                    assert torch.equal(a, b), "C%d differs between passes %d and 0" % (lvl + 2, rep)
+        feats[fuse] = first
+    for lvl, (a, b) in enumerate(zip(feats[False], feats[True])):
+        a, b = a.float(), b.float()
+        scale, err = float(a.abs().max()), float((a - b).abs().max())
+        print("C%d: fused vs separate max |diff| %.3e, scale %.2f" % (lvl + 2, err, scale))
+        assert err <= 2.0 ** -6 * scale
+
+
+@pytest.mark.gpu
 def test_map_of_the_device_paths_against_the_float64_oracle(pkg, state):
     """BASELINE.json's metric asks for 'box mAP vs ref'.  No trained checkpoint or labelled set exists in the reference, so the
     float64 oracle's own detections (its top-scoring boxes after NMS) play the ground truth and each device path is scored
