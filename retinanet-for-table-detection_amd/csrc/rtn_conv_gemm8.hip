@@ -47,12 +47,14 @@ struct G8Params {
     const char* w;
     const float* bias;
     char* out;
-    unsigned w_bytes, out_bytes;
+    const char* res;              // RTN_CONV_RES_SAME: dense [M][res_ld], may be `out` itself; null without
+    const char* mask;             // RTN_CONV_RELU_MASK source: dense [M][mask_ld]; null without
+    unsigned w_bytes, out_bytes, res_bytes, mask_bytes;
     int M, N, Kbytes, nk, nk1;    // K steps in all / from the first source
     int ntiles_m, ntiles_n, ntiles;
     int Hout, Wout;
     float inv_cells, inv_w;
-    int relu, out_ld;
+    int relu, out_ld, res_ld, mask_ld, mask_pre;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -91,7 +93,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int MI, bool STAGGER, bool DUAL>
+// EPI: bit 0 = residual add (the `Add` closing a bottleneck block; accumulated gradient contributions in training), bit 1 = ReLU mask
+// of the tensor being differentiated (rtn_conv2d_dgrad): 16 bytes per lane and row, loaded one row fragment ahead of their use.
+template <int MI, bool STAGGER, bool DUAL, int EPI>
 __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Params p) {
     constexpr int R = 64 * MI;                         // rows of a tile
     static_assert(MI >= 2 && MI <= 3, "the bias table lives in the tail of A stage 0: tiles of at most 192 rows");
@@ -272,22 +276,50 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             a_cur = a_cur == 2 * G8_STAGE ? 0u : a_cur + G8_STAGE;
             b_cur ^= G8_STAGE;
         }
-        // ---- epilogue: ReLU, bf16, 4 MI stores of 16 B per lane
+        // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane
         {
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)p.out, 0, (int)__builtin_amdgcn_readfirstlane((int)p.out_bytes), 0x00020000);
+            const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 1) ? p.res : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 1) ? p.res_bytes : 0u)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 2) ? p.mask : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? p.mask_bytes : 0u)), 0x00020000);
             const int ncol = n0 + wn * 128 + 8 * lrow;
             const bool col_ok = ncol < p.N;
+            u32x4 rq[2][4], mq[2][4];               // residual / mask rows of fragment i (ping-pong: fragment i + 1 is in flight)
+            auto fetch = [&](int i, int par) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    const bool ok = col_ok && m < p.M;
+                    if (EPI & 1) rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.res_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                    if (EPI & 2) mq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                }
+            };
+            if (EPI) fetch(0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (EPI && i + 1 < MI) fetch(i + 1, (i + 1) & 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        v[j] = acc[i][j][r];
-                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r];
+                    if (EPI) {
+                        const u32x4 rw = rq[i & 1][r], mw = mq[i & 1][r];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned mj = (EPI & 2) ? mw[j] : 0x3f803f80u, rj = (EPI & 1) ? rw[j] : 0u;
+                            const bool keep_lo = __uint_as_float(mj << 16) > 0.f, keep_hi = __uint_as_float(mj & 0xffff0000u) > 0.f;
+                            if ((EPI & 2) && p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                            if (EPI & 1) { v[2 * j] += __uint_as_float(rj << 16); v[2 * j + 1] += __uint_as_float(rj & 0xffff0000u); }
+                            if ((EPI & 2) && !p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                     }
                     u32x4 o;
                     o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
@@ -295,6 +327,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                     __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
                     RTN_STORE_GUARD(o)
                 }
+            }
         }
         tile += tstride;
     }
@@ -314,7 +347,10 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
                        int mi_force) {
     if (d->dtype != RTN_BF16 || d->ngroups != 1) return 1;
     if (d->KH != 1 || d->KW != 1 || d->pad_t != 0 || d->pad_l != 0 || d->sy != d->sx || d->sy < 1 || d->sy > 2) return 1;
-    if (d->flags & ~RTN_CONV_RELU) return 1;
+    if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
+    if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
+    const int epi = ((d->flags & RTN_CONV_RES_SAME) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
+    if (epi && s2) return 1;
     if (d->N < 256 || d->N % 256 || d->N > 2048 || d->w_rows != d->N || d->out_ld % 8) return 1;
     if ((d->Crun * 2) % 128 || d->Crun <= 0 || d->pix_stride < d->Crun || (d->pix_stride * 2) % 16) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
@@ -326,6 +362,14 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if ((long long)(g.Hout - 1) * d->sy >= g.Hin || (long long)(g.Wout - 1) * d->sx >= g.Win) return 1;
     if (g.in_elems * 2 >= (long long)G8_OOB || g.out_elems * 2 >= (long long)G8_OOB) return 1;
     if (g.out_elems < (M - 1) * d->out_ld + d->N) return 1;
+    if (epi & 1) {
+        if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride != cells * g.res_ld) return 1;
+        if (g.res_elems < (M - 1) * g.res_ld + d->N || g.res_elems * 2 >= (long long)G8_OOB) return 1;
+    }
+    if (epi & 2) {
+        if (!g.mask || ((uintptr_t)g.mask & 15) || g.mask_ld % 8 || g.mask_img_stride != cells * g.mask_ld) return 1;
+        if (g.mask_elems < (M - 1) * g.mask_ld + d->N || g.mask_elems * 2 >= (long long)G8_OOB) return 1;
+    }
     const long long in_max = (long long)(d->batch - 1) * g.in_img_stride + (long long)(g.Hout - 1) * d->sy * g.in_row_stride +
                              (long long)(g.Wout - 1) * d->sx * d->pix_stride + d->Crun;
     if (in_max > g.in_elems) return 1;
@@ -381,23 +425,30 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     p.inv_w = 1.0f / (float)g.Wout;
     p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
     p.out_ld = d->out_ld;
+    if (epi & 1) { p.res = (const char*)g.res; p.res_bytes = (unsigned)(g.res_elems * 2); p.res_ld = g.res_ld; }
+    if (epi & 2) { p.mask = (const char*)g.mask; p.mask_bytes = (unsigned)(g.mask_elems * 2); p.mask_ld = g.mask_ld; }
+    p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;
-#define RTN_G8_LAUNCH(M_, ST, DU)                                                                        \
+#define RTN_G8_LAUNCH(M_, ST, DU, EP)                                                                    \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, ST, DU>,                   \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, ST, DU, EP>,               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((conv_gemm8_kernel<M_, ST, DU>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
+        hipLaunchKernelGGL((conv_gemm8_kernel<M_, ST, DU, EP>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
     } while (0)
 #define RTN_G8_PICK(M_)                                                                                  \
     do {                                                                                                 \
-        if (s2) { if (stagger) RTN_G8_LAUNCH(M_, true, true); else RTN_G8_LAUNCH(M_, false, true); }     \
-        else    { if (stagger) RTN_G8_LAUNCH(M_, true, false); else RTN_G8_LAUNCH(M_, false, false); }   \
+        if (s2) { if (stagger) RTN_G8_LAUNCH(M_, true, true, 0); else RTN_G8_LAUNCH(M_, false, true, 0); } \
+        else if (!stagger && epi == 0) RTN_G8_LAUNCH(M_, false, false, 0);  /* lockstep variant: A/B only */ \
+        else if (epi == 0) RTN_G8_LAUNCH(M_, true, false, 0);                                            \
+        else if (epi == 1) RTN_G8_LAUNCH(M_, true, false, 1);                                            \
+        else if (epi == 2) RTN_G8_LAUNCH(M_, true, false, 2);                                            \
+        else RTN_G8_LAUNCH(M_, true, false, 3);                                                          \
     } while (0)
     if (mi == 3) RTN_G8_PICK(3); else RTN_G8_PICK(2);
 #undef RTN_G8_PICK

@@ -41,7 +41,9 @@ constexpr unsigned B_STAGE = 32768, A_BASE = 3 * 32768, A_TOGGLE = 0x18000u ^ 0x
 struct H8Group {
     const char* in;
     char* out;
-    unsigned in_bytes, out_bytes;
+    const char* res;              // residual added to the result (RTN_CONV_RES_SAME: dense [M][res_ld]; may be `out` itself) or null
+    const char* mask;             // RTN_CONV_RELU_MASK source (dense [M][mask_ld]) or null
+    unsigned in_bytes, out_bytes, res_bytes, mask_bytes;
     int Hin, Win, M, tile_begin;
     int in_row_stride_b;
     float inv_cells, inv_w;
@@ -54,6 +56,7 @@ struct H8Params {
     unsigned w_bytes;
     int ngroups, ntiles;
     int N, Kbytes, KH, nchunk, pad_t, pad_l, relu, out_ld, pix_b;
+    int res_ld, mask_ld, mask_pre;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -97,7 +100,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // MI = row fragments (16 rows) per wave: tiles of R = 64 MI rows (256 or 192).  The host picks the height that needs the fewest
 // rounds of workgroups x rows (P3 at batch 8: 529 tiles of 256 rows = 3 rounds, 707 tiles of 192 rows = 3 shorter rounds).
-template <int KW, int MI, bool STAGGER>
+// EPI: bit 0 = residual add (keras Add / accumulated gradient contributions), bit 1 = ReLU mask of the tensor being differentiated
+// (the data-gradient launches of the training step, see rtn_conv2d_dgrad): 16 bytes per lane and row, loaded one row fragment ahead.
+template <int KW, int MI, bool STAGGER, int EPI>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
     constexpr int R = 64 * MI;                         // rows of a tile's halo image
     constexpr int TM = R - KW;                         // output rows per tile; halo rows 0 .. R - 2, row R - 1 = zeros
@@ -320,24 +325,54 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             a_cur ^= A_TOGGLE;
             kh = kh1; cc = cc1;
         }
-        // ---- epilogue: ReLU, bf16, 16 stores of 16 B per lane (rows beyond TM / M go to an out-of-range offset and are dropped)
+        // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane (rows beyond TM / M go to an out-of-range
+        // offset and are dropped)
         {
             const H8Group& Gc = p.g[gi];
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
+            const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 1) ? Gc.res : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 1) ? Gc.res_bytes : 0u)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 2) ? Gc.mask : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? Gc.mask_bytes : 0u)), 0x00020000);
             const int ncol = wn * 128 + 8 * lrow;
             const bool col_ok = ncol < p.N;
+            u32x4 rq[2][4], mq[2][4];               // residual / mask rows of fragment i (ping-pong: fragment i + 1 is in flight)
+            auto fetch = [&](int i, int par) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int r = 0; r < 4; ++r) {
+                    const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    const int m = m0 + rloc;
+                    const bool ok = col_ok && rloc < TM && m < Gc.M;
+                    if (EPI & 1) rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.res_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
+                    if (EPI & 2) mq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
+                }
+            };
+            if (EPI) fetch(0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (EPI && i + 1 < MI) fetch(i + 1, (i + 1) & 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
                     const int m = m0 + rloc;
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        v[j] = acc[i][j][r];
-                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r];
+                    if (EPI) {
+                        const u32x4 rw = rq[i & 1][r], mw = mq[i & 1][r];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned mj = (EPI & 2) ? mw[j] : 0x3f803f80u, rj = (EPI & 1) ? rw[j] : 0u;
+                            const bool keep_lo = __uint_as_float(mj << 16) > 0.f, keep_hi = __uint_as_float(mj & 0xffff0000u) > 0.f;
+                            if ((EPI & 2) && p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                            if (EPI & 1) { v[2 * j] += __uint_as_float(rj << 16); v[2 * j + 1] += __uint_as_float(rj & 0xffff0000u); }
+                            if ((EPI & 2) && !p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                     }
                     u32x4 o;
                     o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
@@ -346,6 +381,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
                     RTN_STORE_GUARD(o)
                 }
+            }
         }
         tile += (int)gridDim.x;
         // the staging cursor's halo rows already belong to the next tile (switched in the last group); the pieces it issued for a
@@ -366,7 +402,9 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force) {
     if (d->dtype != RTN_BF16) return 1;
     if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
-    if (d->flags & ~RTN_CONV_RELU) return 1;
+    if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
+    if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
+    const int epi = ((d->flags & RTN_CONV_RES_SAME) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
     if (d->N > 256 || d->N <= 128 || d->w_rows != 256 || d->N % 8 || d->out_ld % 8) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * 2) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
@@ -400,7 +438,21 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         if (!s.in || !s.out || ((uintptr_t)s.in & 15) || ((uintptr_t)s.out & 15)) return 1;
         if (s.in_elems < M * d->Crun || s.out_elems < (M - 1) * d->out_ld + d->N) return 1;
         if (s.in_elems * 2 >= 0xFFFFFF00ll || s.out_elems * 2 >= 0xFFFFFF00ll) return 1;
+        if (epi & 1) {
+            if (!s.res || ((uintptr_t)s.res & 15) || s.res_ld % 8 || s.res_img_stride != cells * s.res_ld) return 1;
+            if (s.res_elems < (M - 1) * s.res_ld + d->N || s.res_elems * 2 >= 0xFFFFFF00ll) return 1;
+        }
+        if (epi & 2) {
+            if (!s.mask || ((uintptr_t)s.mask & 15) || s.mask_ld % 8 || s.mask_img_stride != cells * s.mask_ld) return 1;
+            if (s.mask_elems < (M - 1) * s.mask_ld + d->N || s.mask_elems * 2 >= 0xFFFFFF00ll) return 1;
+        }
+        if (i > 0 && ((epi & 1) && s.res_ld != d->g[0].res_ld)) return 1;
+        if (i > 0 && ((epi & 2) && s.mask_ld != d->g[0].mask_ld)) return 1;
         H8Group& g = p.g[i];
+        g.res = (epi & 1) ? (const char*)s.res : nullptr;
+        g.mask = (epi & 2) ? (const char*)s.mask : nullptr;
+        g.res_bytes = (epi & 1) ? (unsigned)(s.res_elems * 2) : 0u;
+        g.mask_bytes = (epi & 2) ? (unsigned)(s.mask_elems * 2) : 0u;
         g.in = (const char*)s.in;
         g.out = (char*)s.out;
         g.in_bytes = (unsigned)(s.in_elems * 2);
@@ -430,21 +482,32 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
     p.out_ld = d->out_ld;
     p.pix_b = d->pix_stride * 2;
+    p.res_ld = (epi & 1) ? d->g[0].res_ld : 0;
+    p.mask_ld = (epi & 2) ? d->g[0].mask_ld : 0;
+    p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;
-#define RTN_H8_LAUNCH(M_, ST)                                                                            \
+#define RTN_H8_LAUNCH(M_, ST, EP)                                                                        \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST>,                    \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST, EP>,                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
-    if (mi == 4) { if (stagger) RTN_H8_LAUNCH(4, true); else RTN_H8_LAUNCH(4, false); }
-    else         { if (stagger) RTN_H8_LAUNCH(3, true); else RTN_H8_LAUNCH(3, false); }
+#define RTN_H8_PICK(M_)                                                                                  \
+    do {                                                                                                 \
+        if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0);      /* lockstep variant: A/B only */        \
+        else if (epi == 0) RTN_H8_LAUNCH(M_, true, 0);                                                   \
+        else if (epi == 1) RTN_H8_LAUNCH(M_, true, 1);                                                   \
+        else if (epi == 2) RTN_H8_LAUNCH(M_, true, 2);                                                   \
+        else RTN_H8_LAUNCH(M_, true, 3);                                                                 \
+    } while (0)
+    if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
+#undef RTN_H8_PICK
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
     return RTN_OK;

@@ -171,6 +171,76 @@ def test_dgrad_and_wgrad(pkg, handle, dtype, case):
     assert errf <= tol(dtype) * max(1.0, float(wantb.abs().max())) and torch.all(dbf.cpu()[cout:] == 0.25)
 
 
+@pytest.mark.parametrize("mode", ["res", "mask_pre", "res+mask", "res+mask_pre", "mask"])
+@pytest.mark.parametrize("impl,levels,cin,cout,k,B,grid", [
+    (4, [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 3, 2, 0),     # head-tower data gradient: five levels, one grouped launch
+    (4, [(40, 67)], 136, 256, 3, 3, 3),       # N = 136 gradient channels (columns 136..255 of the tile never stored), 3 workgroups
+    (5, [(25, 42)], 256, 128, 1, 8, 0),       # 1x1: gradient of a branch2c layer (K = 128 bytes x 2, N = 256)
+    (5, [(33, 50)], 512, 256, 1, 2, 2),       # two N tiles, 2 workgroups walk all tiles
+])
+def test_dgrad_on_the_persistent_kernels(pkg, handle, monkeypatch, impl, levels, cin, cout, k, B, grid, mode):
+    """The data-gradient launches of the training step on generations 4 / 5 (csrc/rtn_conv_halo8.hip, rtn_conv_gemm8.hip): their
+    register epilogue reads the accumulated gradient (RTN_CONV_RES_SAME, in place) and the forward activation (RTN_CONV_RELU_MASK,
+    before or after the add) 16 bytes per lane.  dX = mask * (dY (*) W^T) + other  |  mask * (dY (*) W^T + other), against float64
+    autograd on the bf16-rounded operands; the launch must really have been the generation asked for."""
+    L = pkg._lib
+    dtype = "bf16"
+    tdt, code = DT[dtype]
+    monkeypatch.setenv("RTN_CONV_IMPL", str(impl))
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    g = torch.Generator().manual_seed(300 + impl + grid)
+    w = q(torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin), dtype)
+    wk, rows = pack_fwd(w, dtype)
+    rows_d = 256 if impl == 4 else cin
+    wd = torch.zeros(rows_d, k * k * cout, dtype=tdt, device=DEV)
+    handle.check(L.lib.rtn_pack_dgrad_weights(handle.raw, wk.data_ptr(), wd.data_ptr(), code, cout, rows, k, k, cin, cout, rows_d))
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w, d.w_rows, d.N, d.KH, d.KW = wd.data_ptr(), rows_d, cin, k, k
+    d.Crun = d.pix_stride = cout
+    d.sy = d.sx = 1
+    d.out_ld = cin
+    d.pad_t = d.pad_l = (k - 1) // 2
+    d.flags = (L.CONV_RES_SAME if "res" in mode else 0) | (L.CONV_RELU_MASK if "mask" in mode else 0) | \
+        (L.CONV_MASK_PRE if "pre" in mode else 0)
+    keep, outs, wants = [], [], []
+    for gi, (H, W) in enumerate(levels):
+        x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype).requires_grad_(True)
+        y = fwd_ref(x, w, 1, (k - 1) // 2, (k - 1) // 2, H, W)
+        dy = q(torch.randn(B, H, W, cout, generator=g, dtype=torch.float64), dtype)
+        other = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+        act = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+        act[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0, 0.5, 0.0])     # zeros of either sign do not pass
+        dx = torch.autograd.grad(y, x, dy)[0]
+        keepm = (act > 0) if "mask" in mode else torch.ones_like(act, dtype=torch.bool)
+        if "res" in mode:
+            dx = dx * keepm + other if "pre" in mode else (dx + other) * keepm
+        else:
+            dx = dx * keepm
+        dyd = dy.to(tdt).to(DEV).contiguous()
+        dxd = other.to(tdt).to(DEV).contiguous() if "res" in mode else torch.full((B, H, W, cin), -77.0, dtype=tdt, device=DEV)
+        actd = act.to(tdt).to(DEV).contiguous()
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = dyd.data_ptr(), dyd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cout, W * cout
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems, grp.out_img_stride = dxd.data_ptr(), dxd.numel(), H * W * cin
+        if "res" in mode:
+            grp.res, grp.res_elems, grp.res_img_stride, grp.res_ld = dxd.data_ptr(), dxd.numel(), H * W * cin, cin
+        if "mask" in mode:
+            grp.mask, grp.mask_elems, grp.mask_img_stride, grp.mask_ld = actd.data_ptr(), actd.numel(), H * W * cin, cin
+        d.g[gi] = grp
+        keep += [dyd, actd]
+        outs.append(dxd)
+        wants.append(dx)
+    handle.check(L.lib.rtn_conv2d_dgrad(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == impl
+    for o, want in zip(outs, wants):
+        err = float((o.cpu().double() - want).abs().max())
+        assert err <= tol(dtype) * max(1.0, float(want.abs().max())), "dgrad err %.3e" % err
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wgrad_grouped_levels_and_padded_head_output(pkg, handle, dtype):
     """Shared head weights: one wgrad launch over five pyramid levels; dY of the 36-channel output padded to 64."""
