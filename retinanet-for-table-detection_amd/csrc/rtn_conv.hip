@@ -1284,7 +1284,7 @@ int rtn_env_int(const char* name, int dflt) {
 }
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
-    return (v >= 1 && v <= 5) ? v : 0;                 // 4 / 5 = the persistent 8-phase kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip) where they apply
+    return (v >= 1 && v <= 6) ? v : 0;                 // 4 / 5 / 6 = the persistent kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip / rtn_conv_halon.hip) where they apply
 }
 
 int ilog2_exact(int v) {
@@ -1433,6 +1433,17 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
         }
     }
+    // Sixth generation (rtn_conv_halon.hip): the head OUTPUT convolutions (3x3, <= 48 channels, f32 result in the concatenated
+    // tensor).  RTN_CONV_HN=0 turns it off, RTN_CONV_IMPL=6 forces it.
+    if (!query && !s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16 && d->N <= 48 && (d->flags & RTN_CONV_OUT_F32)) {
+        const int hn = rtn_env_int("RTN_CONV_HN", 1);
+        const int forced = rtn_conv_impl_override();
+        if (forced == 6 || (forced == 0 && hn != 0)) {
+            const int rc = rtn_conv_halon_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), forced == 6);
+            if (rc == RTN_OK) h->last_conv_impl = 6;
+            if (rc <= 0) return rc;
+        }
+    }
     // Fifth generation (rtn_conv_gemm8.hip): the 1x1 layers with N % 256 == 0 and a bias / ReLU epilogue, one or two sources.
     // RTN_CONV_G8=0 turns it off, RTN_CONV_IMPL=5 forces it; RTN_CONV_G8_MI pins the tile height (2 | 3 row fragments per wave).
     if (!query && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16 && d->KH == 1 && d->KW == 1) {
@@ -1446,7 +1457,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         }
     }
     if (impl == 4) impl = halo_ok ? 3 : 2;
-    if (impl == 5) impl = 2;
+    if (impl == 5 || impl == 6) impl = 2;
     const int TM = impl == 3 ? BM2 - (d->KW - 1) : (impl == 2 ? BM2 : BM);
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];

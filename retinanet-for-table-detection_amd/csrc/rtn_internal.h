@@ -48,6 +48,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
 // two (K-concatenated) sources, stride 1 or 2.
 int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2, int grid_limit, bool stagger, bool forced,
                        int mi_force);
+int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool forced);
 
 static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }
 

@@ -323,6 +323,32 @@ def test_head_output_concat(pkg, handle, dtype, cout, sig):
     check(gots, wants, ld, n, dtype)
 
 
+@pytest.mark.parametrize("levels,cin,cout,sig,B,grid", [
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 36, False, 2, 0),     # pyramid_regression: 16-byte f32 stores
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 9, True, 2, 0),       # pyramid_classification: 9 channels, dword stores, sigmoid
+    ([(40, 67), (20, 34)], 256, 36, False, 3, 3),      # 3 workgroups walk ~12 tiles each: the stage ring crosses tiles and levels
+    ([(25, 42), (13, 21)], 128, 18, True, 2, 1),       # two anchors' worth of channels (2 fragments), two chunks per tap, ONE workgroup
+    ([(7, 300)], 64, 48, False, 1, 2),                 # rows longer than a tile, one chunk per tap, 3 full fragments
+    ([(3, 5)], 256, 4, False, 1, 0),                   # a single, mostly empty tile
+])
+def test_persistent_head_output_kernel(pkg, handle, monkeypatch, levels, cin, cout, sig, B, grid):
+    """Generation 6 (csrc/rtn_conv_halon.hip): the head output convolutions (3x3, <= 48 channels, f32 result at the level offsets
+    of the concatenated tensor) as a persistent kernel with transposed products.  Against the float64 convolution of the
+    bf16-rounded operands; the launch must really have been generation 6; repeated launches give the same bits."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "6")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    flags = L.CONV_OUT_F32 | (L.CONV_SIGMOID if sig else 0)
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, None, B=B, concat=True, seed=30 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 6
+    check(gots, wants, ld, n, "bf16")
+    for _ in range(3):
+        again, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, None, B=B, concat=True, seed=30 + grid,
+                                  reference=False)
+        for a, b in zip(again, gots):
+            assert torch.equal(a, b)
+
+
 def test_conv_rejects_bad_descriptors(pkg, handle):
     L = pkg._lib
     dev = torch.device("cuda")
