@@ -1278,10 +1278,6 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
 // Tuning knobs, read on every call so one process can A/B them: RTN_CONV_IMPL=1|2 forces a kernel generation
 // (unset/0 = heuristic); RTN_CONV_IL=1 interleaves the staging DMA issues between MFMA groups
 // instead of issuing them ahead of the MFMA block (measured slower: 1084 vs 1226 TF/s on the head layers).
-int rtn_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
     return (v >= 1 && v <= 6) ? v : 0;                 // 4 / 5 / 6 = the persistent kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip / rtn_conv_halon.hip) where they apply
@@ -1295,6 +1291,12 @@ int ilog2_exact(int v) {
 }
 
 }  // namespace
+
+int rtn_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
 
 // `query` != nullptr: no launch; *query = bytes of d->workspace this launch can use (the K-split paths below).
 static constexpr long long kMaxConvWorkspace = 256ll << 20;
@@ -1424,12 +1426,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     // P4 0.062 -> 0.047.  RTN_CONV_H8=0 turns it off (A/B), RTN_CONV_IMPL=4 forces it like any other generation;
     // RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers), RTN_CONV_H8_STAGGER=0 runs
     // the two wave groups in lockstep (A/B: 0.181 ms on the head layer).
-    if (!query && !s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16) {
+    if (!s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16) {
         const int h8 = rtn_env_int("RTN_CONV_H8", 1);
         const int forced = rtn_conv_impl_override();
         if (forced == 4 || (forced == 0 && h8 != 0)) {
-            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4, rtn_env_int("RTN_CONV_H8_MI", 0));
-            if (rc == RTN_OK) h->last_conv_impl = 4;
+            const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4,
+                                              rtn_env_int("RTN_CONV_H8_MI", 0), ws_ptr, ws_cap, query, rtn_env_int("RTN_CONV_H8_KSPLIT", 0));
+            if (rc == RTN_OK && !query) h->last_conv_impl = 4;
             if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
         }
     }

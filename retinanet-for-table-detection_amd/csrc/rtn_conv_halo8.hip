@@ -57,6 +57,13 @@ struct H8Params {
     int ngroups, ntiles;
     int N, Kbytes, KH, nchunk, pad_t, pad_l, relu, out_ld, pix_b;
     int res_ld, mask_ld, mask_pre;
+    // work items: (row tile, column block of 256 channels, K slice).  ncb = S = 1 for the layers this kernel was built for; the
+    // small-M long-K layers (res5 branch2b: 34 row tiles x 2 column blocks, 72 K steps) are cut into S slices of gps (kh, chunk)
+    // groups whose f32 partial sums go to slab[s][M][slab_ld] and are summed in slice order by ksplit_finish_kernel
+    int ncb, S, gps, nitems, xcd;
+    float* slab;
+    unsigned slab_slice_bytes;
+    int slab_ld;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -102,7 +109,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // rounds of workgroups x rows (P3 at batch 8: 529 tiles of 256 rows = 3 rounds, 707 tiles of 192 rows = 3 shorter rounds).
 // EPI: bit 0 = residual add (keras Add / accumulated gradient contributions), bit 1 = ReLU mask of the tensor being differentiated
 // (the data-gradient launches of the training step, see rtn_conv2d_dgrad): 16 bytes per lane and row, loaded one row fragment ahead.
-template <int KW, int MI, bool STAGGER, int EPI>
+// SPLIT: the work items carry a column block and a K slice (see H8Params); accumulators start at zero, the bias is added by the
+// epilogue (S = 1) or by the finish kernel (S > 1).
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
     constexpr int R = 64 * MI;                         // rows of a tile's halo image
     constexpr int TM = R - KW;                         // output rows per tile; halo rows 0 .. R - 2, row R - 1 = zeros
@@ -227,15 +236,45 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
     }
 
-    // ---- prologue: halo of (tile, group 0), B tiles of steps 0 and 1 (the last piece of step 1 goes out in step 0, phase 1)
-    int tile = blockIdx.x;
-    stage_tile(tile);
+    // ---- work items.  Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), and neighbouring row tiles read each
+    // other's halo rows (kh = 0 / 2 reach one image row up / down): item(v) hands every XCD a CONTIGUOUS range of items, so that
+    // those re-reads hit the XCD's own L2 instead of fetching the rows again from HBM (measured with FETCH_SIZE: 274 MB per
+    // head-tower launch against 93 MB of input before).  v -> item is a bijection on [0, nitems) for any grid size.
+    auto item_of = [&](int v) {
+        if (v >= p.nitems || !p.xcd) return v;
+        const int x = v & 7, j = v >> 3, base = p.nitems >> 3, rem = p.nitems & 7;
+        return x * base + (x < rem ? x : rem) + j;
+    };
+    // item -> row tile, byte offset of its column block inside the weights, first (kh, chunk) group of its K slice
+    auto item_decode = [&](int it, int& rt, int& cb, int& sl, unsigned& cboff, int& kh0, int& cc0) {
+        if (!SPLIT || it >= p.nitems) { rt = it >= p.nitems ? p.ntiles : it; cb = 0; sl = 0; cboff = 0u; kh0 = 0; cc0 = 0; return; }
+        const int per = p.ncb * p.S;
+        rt = it / per;
+        const int rem = it - rt * per;
+        cb = rem / p.S;
+        sl = rem - cb * p.S;
+        cboff = (unsigned)cb * 256u * (unsigned)p.Kbytes;
+        const int g0 = sl * p.gps;
+        kh0 = g0 / nchunk;
+        cc0 = g0 - kh0 * nchunk;
+    };
+    const int gps = SPLIT ? p.gps : G;                 // groups per item
+
+    // ---- prologue: halo of the first group, B tiles of steps 0 and 1 (the last piece of step 1 goes out in step 0, phase 1)
+    int vidx = blockIdx.x;
+    int rt, cb, sl, kh0, cc0;
+    unsigned cboff;
+    item_decode(item_of(vidx), rt, cb, sl, cboff, kh0, cc0);
+    stage_tile(rt);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) stage_a(i, 0, 0, A_BASE);
+    for (int i = 0; i < MI; ++i) stage_a(i, kh0, cc0, A_BASE);
+    {
+        const unsigned kc0 = cboff + (unsigned)((kh0 * KW * nchunk + cc0) * 128);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) stage_b(d, 0u, 0);
+        for (int d = 0; d < 4; ++d) stage_b(d, kc0, 0);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) stage_b(d, (unsigned)(nchunk * 128), 1);
+        for (int d = 0; d < 3; ++d) stage_b(d, kc0 + (unsigned)(nchunk * 128), 1);
+    }
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
@@ -295,25 +334,28 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     static_assert(KW == 3 && MI >= 2 && MI <= 4, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3, MI <= 4");
 
     const unsigned kw_stride = (unsigned)(nchunk * 128);           // K bytes between the taps of a kernel row
-    while (tile < p.ntiles) {
+    while (rt < p.ntiles) {
         int gi, m0;
-        compute_tile(tile, gi, m0);
+        compute_tile(rt, gi, m0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
-        int kh = 0, cc = 0;
+            for (int j = 0; j < 8; ++j) acc[i][j] = SPLIT ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
+        int kh = kh0, cc = cc0;
+        int rt1 = rt, cb1 = cb, sl1 = sl;
+        unsigned cboff1 = cboff;
 #pragma unroll 1
-        for (int g = 0; g < G; ++g) {
-            // the next group (kh1, cc1): of this tile, or group 0 of the workgroup's next tile
+        for (int g = 0; g < gps; ++g) {
+            // the next group (kh1, cc1): of this item, or the first group of the workgroup's next item
             int kh1 = kh, cc1 = cc + 1;
             if (cc1 == nchunk) { cc1 = 0; ++kh1; }
-            if (g + 1 == G) {
-                kh1 = 0; cc1 = 0;
-                stage_tile(tile + (int)gridDim.x);
+            if (g + 1 == gps) {
+                vidx += (int)gridDim.x;
+                item_decode(item_of(vidx), rt1, cb1, sl1, cboff1, kh1, cc1);
+                stage_tile(rt1);
             }
-            const unsigned kcol_g = (unsigned)((kh * KW * nchunk + cc) * 128);
-            const unsigned kcol_g1 = (unsigned)((kh1 * KW * nchunk + cc1) * 128);
+            const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
+            const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
             H8_STEP(0)
             H8_STEP(1)
             H8_STEP(2)
@@ -325,9 +367,32 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             a_cur ^= A_TOGGLE;
             kh = kh1; cc = cc1;
         }
+        kh0 = kh; cc0 = cc;                            // the next item starts at the group the cursor already points to
         // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane (rows beyond TM / M go to an out-of-range
         // offset and are dropped)
-        {
+        if (SPLIT && p.S > 1) {
+            // f32 partial sums of this K slice -> slab[sl][m][256 cb + channel], 2 x 16 B per lane and row
+            const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)p.slab + (size_t)sl * p.slab_slice_bytes), 0, (int)__builtin_amdgcn_readfirstlane((int)p.slab_slice_bytes), 0x00020000);
+            const int gcol = cb * 256 + wn * 128 + 8 * lrow;
+            const int Mg = p.g[gi].M;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    const int m = m0 + rloc;
+                    const bool ok = gcol < p.slab_ld && rloc < TM && m < Mg;
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.slab_ld + (unsigned)gcol) * 4u : OOB;
+                    u32x4 o0, o1;
+                    o0.x = __float_as_uint(acc[i][0][r]); o0.y = __float_as_uint(acc[i][1][r]); o0.z = __float_as_uint(acc[i][2][r]); o0.w = __float_as_uint(acc[i][3][r]);
+                    o1.x = __float_as_uint(acc[i][4][r]); o1.y = __float_as_uint(acc[i][5][r]); o1.z = __float_as_uint(acc[i][6][r]); o1.w = __float_as_uint(acc[i][7][r]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, slab_rsrc, (int)off, 0, 0);
+                    RTN_STORE_GUARD(o0)
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, slab_rsrc, (int)(ok ? off + 16u : OOB), 0, 0);
+                    RTN_STORE_GUARD(o1)
+                }
+        } else {
             const H8Group& Gc = p.g[gi];
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
@@ -335,8 +400,17 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                 (void*)((EPI & 1) ? Gc.res : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 1) ? Gc.res_bytes : 0u)), 0x00020000);
             const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((EPI & 2) ? Gc.mask : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? Gc.mask_bytes : 0u)), 0x00020000);
-            const int ncol = wn * 128 + 8 * lrow;
+            const int ncol = (SPLIT ? cb * 256 : 0) + wn * 128 + 8 * lrow;
             const bool col_ok = ncol < p.N;
+            float bias_e[8];                        // SPLIT: the accumulators started at zero
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bias_e[j] = 0.f;
+            if (SPLIT && p.bias && col_ok) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + ncol + 4);
+                bias_e[0] = b0.x; bias_e[1] = b0.y; bias_e[2] = b0.z; bias_e[3] = b0.w;
+                bias_e[4] = b1.x; bias_e[5] = b1.y; bias_e[6] = b1.z; bias_e[7] = b1.w;
+            }
             u32x4 rq[2][4], mq[2][4];               // residual / mask rows of fragment i (ping-pong: fragment i + 1 is in flight)
             auto fetch = [&](int i, int par) {
 #pragma unroll
@@ -358,7 +432,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     const int m = m0 + rloc;
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r];
+                    for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r] + (SPLIT ? bias_e[j] : 0.f);
                     if (EPI) {
                         const u32x4 rw = rq[i & 1][r], mw = mq[i & 1][r];
 #pragma unroll
@@ -383,9 +457,9 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                 }
             }
         }
-        tile += (int)gridDim.x;
-        // the staging cursor's halo rows already belong to the next tile (switched in the last group); the pieces it issued for a
-        // tile past the end are zeros from out-of-range offsets
+        rt = rt1; cb = cb1; sl = sl1; cboff = cboff1;
+        // the staging cursor's halo rows already belong to the next item (switched in the last group); the pieces it issued for an
+        // item past the end are zeros from out-of-range offsets
     }
 #undef H8_STEP
 #undef H8_MFMA
@@ -398,34 +472,59 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 }  // namespace
 
 // Launcher.  Returns RTN_OK after a launch, 1 when the layer is not one this kernel takes (the caller falls through to the other
-// kernels), < 0 on a launch error.  `force`: take every eligible layer (tests), otherwise the caller decides.
-int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force) {
+// kernels), < 0 on a launch error.  `forced`: take every eligible layer (tests), otherwise the caller decides.  `ws` / `ws_cap`: the
+// caller-owned workspace (K-slice slabs); `query` != nullptr: no launch, *query = workspace bytes this layer would use.
+// `ksplit_force`: 0 = cost model, 1 = never slice, n > 1 = n slices when n divides the group count.
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
+                       long long ws_cap, size_t* query, int ksplit_force) {
+    if (query) *query = 0;
     if (d->dtype != RTN_BF16) return 1;
     if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
     if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
     if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
     const int epi = ((d->flags & RTN_CONV_RES_SAME) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
-    if (d->N > 256 || d->N <= 128 || d->w_rows != 256 || d->N % 8 || d->out_ld % 8) return 1;
+    const int ncb = (d->N + 255) / 256;                // column blocks of 256 channels
+    if (d->N <= 128 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;   // weight rows past w_rows read as zeros (descriptor range)
+    if (ncb > 1 && epi) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * 2) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
     const int nchunk = d->Crun * 2 / 128;
+    const int G = d->KH * nchunk;
     const long long Kbytes = (long long)d->KH * d->KW * d->Crun * 2;
-    if (Kbytes * 256 >= 0xFFFFFF00ll) return 1;
+    if (Kbytes * 256 * ncb >= 0xFFFFFF00ll) return 1;                  // the staging offsets of the last column block
     H8Params p;
     memset(&p, 0, sizeof(p));
     const int cus = h->num_cus > 0 ? h->num_cus : 256;
-    // tile height: rounds of workgroups x (rows + a fixed per-tile cost); RTN_CONV_H8_MI pins it (A/B, tests)
-    int mi = mi_force;
-    if (mi < 3 || mi > 4) {
+    long long Mtot = 0;
+    for (int i = 0; i < d->ngroups; ++i) Mtot += (long long)d->g[i].Hout * d->g[i].Wout * d->batch;
+    // Tile height (rows = 64 mi) and K slices by a cost model in microseconds: rounds of workgroups x K steps of an item (+ 5 for its
+    // prologue / epilogue) x 1.53 us per 256-row step, + for S > 1 the finish launch and the slabs' round trip at 4 TB/s.
+    // RTN_CONV_H8_MI / RTN_CONV_H8_KSPLIT pin them (A/B, tests).
+    const bool can_split = d->ngroups == 1 && epi == 0 && ksplit_force != 1 && (ws_cap > 0 || query);
+    const long long slab_ld = 256ll * ncb;
+    int mi = 0, S = 1;
+    {
         double best = 0;
         for (int cand = 4; cand >= 3; --cand) {
+            if (mi_force >= 3 && mi_force <= 4 && cand != mi_force) continue;
             long long t = 0;
             for (int i = 0; i < d->ngroups; ++i) t += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 64 * cand - 4) / (64 * cand - 3);
-            const double cost = (double)((t + cus - 1) / cus) * (cand + 0.3);
-            if (cand == 4 || cost < best * 0.97) { best = cost; mi = cand; }
+            const double step_us = 1.53 * (cand + 0.3) / 4.3;
+            for (int sc = 1; sc <= 8; ++sc) {
+                if (sc > 1 && (!can_split || G % sc || (ksplit_force > 1 && sc != ksplit_force))) continue;
+                if (sc == 1 && ksplit_force > 1 && can_split && G % ksplit_force == 0) continue;
+                if (sc > 1 && (double)sc * Mtot * slab_ld * 4 > (double)(query ? (256ll << 20) : ws_cap)) continue;
+                const long long items = t * ncb * sc;
+                double cost = (double)((items + cus - 1) / cus) * (3.0 * G / sc + 5.0) * step_us;
+                if (sc > 1) cost += 4.0 + ((double)sc * Mtot * slab_ld * 4 + (double)Mtot * d->N * 2) / 4.0e6;
+                if (mi == 0 || cost < best * 0.97) { best = cost; mi = cand; S = sc; }
+            }
         }
+        if (mi == 0) return 1;
     }
+    if (S > 1 && !query && (!ws || ((uintptr_t)ws & 15))) return 1;
+    const bool split = ncb > 1 || S > 1;
     const int TM = 64 * mi - 3;
     long long tiles = 0;
     for (int i = 0; i < d->ngroups; ++i) {
@@ -464,14 +563,18 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         g.inv_w = 1.0f / (float)s.Win;
         tiles += (M + TM - 1) / TM;
     }
-    if (tiles < 1 || tiles > 0x3fffffff) return 1;
+    const long long items = tiles * ncb * S;
+    if (tiles < 1 || items > 0x3fffffff) return 1;
     // one 256 x 256 tile per CU: below a quarter of the chip the narrow tiles of generation 2 (four times the workgroups) are
-    // faster (P5 at batch 8: 34 tiles, 0.049 ms here against 0.037 ms); from half the chip on this kernel wins (res4 3x3, P4:
-    // 133 tiles, 0.054 against 0.067 ms)
-    if (!forced && tiles * 4 < cus) return 1;
+    // faster (P5 at batch 8 unsliced: 34 tiles, 0.049 ms here against 0.037 ms); from half the chip on this kernel wins (res4 3x3,
+    // P4: 133 tiles, 0.054 against 0.067 ms)
+    if (!forced && items * 4 < cus) return 1;
+    const long long slice_bytes = Mtot * slab_ld * 4;
+    if (S > 1 && slice_bytes >= 0xFFFFFF00ll) return 1;
+    if (query) { *query = S > 1 ? (size_t)(slice_bytes * S) : 0; return RTN_OK; }
     p.w = (const char*)d->w;
     p.bias = d->bias;
-    p.w_bytes = (unsigned)(Kbytes * 256);
+    p.w_bytes = (unsigned)(Kbytes * d->w_rows);
     p.ngroups = d->ngroups;
     p.ntiles = (int)tiles;
     p.N = d->N;
@@ -485,30 +588,37 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.res_ld = (epi & 1) ? d->g[0].res_ld : 0;
     p.mask_ld = (epi & 2) ? d->g[0].mask_ld : 0;
     p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
+    p.ncb = ncb; p.S = S; p.gps = G / S; p.nitems = (int)items;
+    p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;       // A/B knob: 0 = workgroup b starts at item b
+    p.slab = S > 1 ? ws : nullptr;
+    p.slab_slice_bytes = S > 1 ? (unsigned)slice_bytes : 0u;
+    p.slab_ld = (int)slab_ld;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
-    if (grid > p.ntiles) grid = p.ntiles;
-#define RTN_H8_LAUNCH(M_, ST, EP)                                                                        \
+    if (grid > p.nitems) grid = p.nitems;
+#define RTN_H8_LAUNCH(M_, ST, EP, SP)                                                                    \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST, EP>,                \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST, EP, SP>,            \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP, SP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
-        if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0);      /* lockstep variant: A/B only */        \
-        else if (epi == 0) RTN_H8_LAUNCH(M_, true, 0);                                                   \
-        else if (epi == 1) RTN_H8_LAUNCH(M_, true, 1);                                                   \
-        else if (epi == 2) RTN_H8_LAUNCH(M_, true, 2);                                                   \
-        else RTN_H8_LAUNCH(M_, true, 3);                                                                 \
+        if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                     \
+        else if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0, false);      /* lockstep variant: A/B only */ \
+        else if (epi == 0) RTN_H8_LAUNCH(M_, true, 0, false);                                            \
+        else if (epi == 1) RTN_H8_LAUNCH(M_, true, 1, false);                                            \
+        else if (epi == 2) RTN_H8_LAUNCH(M_, true, 2, false);                                            \
+        else RTN_H8_LAUNCH(M_, true, 3, false);                                                          \
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
+    if (S > 1) return rtn_conv_ksplit_finish(h, ws, S, Mtot, d->N, (int)slab_ld, d->bias, p.relu, d->g[0].out, d->out_ld);
     return RTN_OK;
 }

@@ -57,7 +57,7 @@ struct HNParams {
     const float* bias;
     unsigned w_bytes;
     int ngroups, ntiles;
-    int N, Kbytes, nchunk, pad_t, pad_l, relu, sigmoid, out_ld, pix_b, vec;
+    int N, Kbytes, nchunk, pad_t, pad_l, relu, sigmoid, out_ld, pix_b, vec, xcd;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -151,7 +151,14 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
             }
         }
     };
-    int st_tile = blockIdx.x, st_kh = 0, st_cc = 0;
+    // workgroup b runs on XCD b % 8: tile_of hands every XCD a contiguous range of tiles, so that the halo rows neighbouring tiles
+    // share (kernel rows 0 / 2 reach one image row up / down) are fetched into one L2 only (see rtn_conv_halo8.hip)
+    auto tile_of = [&](int v) {
+        if (v >= p.ntiles || !p.xcd) return v;
+        const int x = v & 7, j = v >> 3, base = p.ntiles >> 3, rem = p.ntiles & 7;
+        return x * base + (x < rem ? x : rem) + j;
+    };
+    int st_v = blockIdx.x, st_kh = 0, st_cc = 0;
     unsigned st_ring = 0;                              // LDS offset of the stage being filled
     auto issue_stage = [&]() {
         const int dy = st_kh - p.pad_t;
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
             st_cc = 0;
             if (++st_kh == 3) {
                 st_kh = 0;
-                st_tile += (int)gridDim.x;
-                stage_tile(st_tile);
+                st_v += (int)gridDim.x;
+                stage_tile(tile_of(st_v));
             }
         }
     };
@@ -188,14 +195,15 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
     // weight fragment address inside a stage: row kw * 16 NF + 16 f + lrow, chunk (4 ks + kq) ^ (lrow & 7)
     const unsigned w_lane = HN_HALO + (unsigned)(lrow * 128 + ((kq ^ (lrow & 7)) << 4));
 
-    stage_tile(st_tile);
+    stage_tile(tile_of(st_v));
     issue_stage();
     issue_stage();
 
     unsigned c_ring = 0;                               // stage the multiplies read
-    int tile = blockIdx.x;
+    int cv = blockIdx.x;
     bool first = true;
-    while (tile < p.ntiles) {
+    while (cv < p.ntiles) {
+        const int tile = tile_of(cv);
         int gi = 0;
 #pragma unroll
         for (int i = 1; i < RTN_MAX_GROUPS; ++i)
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
                     }
                 }
         }
-        tile += (int)gridDim.x;
+        cv += (int)gridDim.x;
         first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
@@ -362,6 +370,7 @@ int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.out_ld = d->out_ld;
     p.pix_b = d->pix_stride * 2;
     p.vec = vec ? 1 : 0;
+    p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;

@@ -42,7 +42,12 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 
 // rtn_conv_halo8.hip: persistent 8-phase kernel for the stride-1 3x3 layers with 129..256 output channels (head towers, P3-P5,
 // res4 branch2b).  RTN_OK = launched, 1 = not a layer this kernel takes, < 0 = error.
-int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force);
+// integer environment knob, read on every call so that one process can A/B kernel variants (tools/ab_conv.py)
+int rtn_env_int(const char* name, int dflt);
+int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
+                       long long ws_cap, size_t* query, int ksplit_force);
+int rtn_conv_ksplit_finish(rtn_handle_t h, const float* slab, int S, long long M, int N, int ld, const float* bias, int relu, void* out,
+                           int out_ld);
 
 // rtn_conv_gemm8.hip: the same schedule as a plain GEMM for the 1x1 layers with N % 256 == 0 and a bias / ReLU epilogue, one or
 // two (K-concatenated) sources, stride 1 or 2.

@@ -290,6 +290,32 @@ def test_persistent_gemm8_kernel(pkg, handle, monkeypatch, levels, cin, cout, st
         assert float((a - b).abs().max()) <= 4e-2 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("levels,cin,cout,B,grid,mi,ksplit", [
+    ([(25, 42)], 512, 512, 2, 0, 0, 0),       # res5 branch2b: two column blocks; tile height and K slices by the cost model
+    ([(25, 42)], 512, 512, 2, 3, 4, 1),       # ... unsliced: the epilogue adds the bias (accumulators of a block item start at zero)
+    ([(25, 42)], 512, 512, 1, 5, 3, 3),       # ... 3 slices (one kernel row each), 5 workgroups walk ~36 items each
+    ([(25, 42)], 256, 320, 2, 2, 4, 6),       # second column block a quarter full, weight rows past 384 come from the range check
+    ([(13, 21)], 256, 256, 3, 0, 0, 4),       # one column block, 4 slices of 3 groups: P5-like
+    ([(40, 67)], 128, 256, 1, 7, 3, 2),       # two chunks per tap: slices of 3 groups start in the middle of a kernel row
+])
+def test_halo8_column_blocks_and_k_slices(pkg, handle, monkeypatch, levels, cin, cout, B, grid, mi, ksplit):
+    """Generation 4 on the small-M, long-K layers: work items = (row tile, column block of 256 channels, K slice); the slices' f32
+    partial sums go to caller-owned slabs (rtn_conv2d_workspace_bytes) and are added in slice order by ksplit_finish_kernel, so
+    repeated launches give the same bits.  RTN_CONV_H8_KSPLIT pins the slice count (1 = never)."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "4")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_H8_MI", str(mi))
+    monkeypatch.setenv("RTN_CONV_H8_KSPLIT", str(ksplit))
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", L.CONV_RELU, None, B=B, seed=120 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
+    check(gots, wants, ld, n, "bf16")
+    for _ in range(3):
+        again, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", L.CONV_RELU, None, B=B, seed=120 + grid, reference=False)
+        for a, b in zip(again, gots):
+            assert torch.equal(a, b)
+
+
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
