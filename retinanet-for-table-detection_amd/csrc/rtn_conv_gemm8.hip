@@ -55,6 +55,11 @@ struct G8Params {
     int Hout, Wout;
     float inv_cells, inv_w;
     int relu, out_ld, res_ld, mask_ld, mask_pre;
+    // RTN_CONV_RES_UPSAMPLE (EPI bit 0 with res_up): the residual is the coarser pyramid level, read at
+    // (min(floor(oy * rs_h), Hres - 1), min(floor(ox * rs_w), Wres - 1)) — UpsampleLike + Add of the FPN laterals (model/layers.py:89-98)
+    int res_up, Hres, Wres;
+    unsigned res_img_stride;      // elements between images of `res`
+    float rs_h, rs_w;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -292,7 +297,19 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
                     const bool ok = col_ok && m < p.M;
-                    if (EPI & 1) rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.res_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                    if (EPI & 1) {
+                        unsigned rrow = (unsigned)m * (unsigned)p.res_ld;
+                        if (p.res_up) {
+                            int b, rem, oy, ox;
+                            divmod24(ok ? m : 0, p.Hout * p.Wout, p.inv_cells, b, rem);
+                            divmod24(rem, p.Wout, p.inv_w, oy, ox);
+                            int sy_ = (int)floorf((float)oy * p.rs_h), sx_ = (int)floorf((float)ox * p.rs_w);
+                            sy_ = sy_ < p.Hres - 1 ? sy_ : p.Hres - 1;
+                            sx_ = sx_ < p.Wres - 1 ? sx_ : p.Wres - 1;
+                            rrow = (unsigned)b * p.res_img_stride + (unsigned)(sy_ * p.Wres + sx_) * (unsigned)p.res_ld;
+                        }
+                        rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? (rrow + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                    }
                     if (EPI & 2) mq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
                 }
             };
@@ -347,11 +364,17 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
                        int mi_force) {
     if (d->dtype != RTN_BF16 || d->ngroups != 1) return 1;
     if (d->KH != 1 || d->KW != 1 || d->pad_t != 0 || d->pad_l != 0 || d->sy != d->sx || d->sy < 1 || d->sy > 2) return 1;
-    if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
+    if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
     if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
-    const int epi = ((d->flags & RTN_CONV_RES_SAME) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
+    if ((d->flags & RTN_CONV_RES_SAME) && (d->flags & RTN_CONV_RES_UPSAMPLE)) return 1;
+    const bool res_up = d->flags & RTN_CONV_RES_UPSAMPLE;
+    const int epi = ((d->flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
     if (epi && s2) return 1;
-    if (d->N < 256 || d->N % 256 || d->N > 2048 || d->w_rows != d->N || d->out_ld % 8) return 1;
+    // N = 128: half of the 256-column tile multiplies zeros (weight rows past w_rows come from the descriptor's range check); only
+    // worth it where the layer is bound by its pixel traffic (RTN_CONV_G8_N128, A/B)
+    const bool n128 = d->N == 128 && (forced || rtn_env_int("RTN_CONV_G8_N128", 0) != 0);
+    if (!n128 && (d->N < 256 || d->N % 256)) return 1;
+    if (d->N > 2048 || d->w_rows != d->N || d->out_ld % 8) return 1;
     if ((d->Crun * 2) % 128 || d->Crun <= 0 || d->pix_stride < d->Crun || (d->pix_stride * 2) % 16) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
     const rtn_conv_group_t& g = d->g[0];
@@ -362,9 +385,14 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if ((long long)(g.Hout - 1) * d->sy >= g.Hin || (long long)(g.Wout - 1) * d->sx >= g.Win) return 1;
     if (g.in_elems * 2 >= (long long)G8_OOB || g.out_elems * 2 >= (long long)G8_OOB) return 1;
     if (g.out_elems < (M - 1) * d->out_ld + d->N) return 1;
-    if (epi & 1) {
+    if ((epi & 1) && !res_up) {
         if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride != cells * g.res_ld) return 1;
         if (g.res_elems < (M - 1) * g.res_ld + d->N || g.res_elems * 2 >= (long long)G8_OOB) return 1;
+    }
+    if (res_up) {
+        if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride % 8 || g.Hres < 1 || g.Wres < 1) return 1;
+        if (g.res_img_stride < 0 || (long long)(d->batch - 1) * g.res_img_stride + ((long long)g.Hres * g.Wres - 1) * g.res_ld + d->N > g.res_elems) return 1;
+        if (g.res_elems * 2 >= (long long)G8_OOB) return 1;
     }
     if (epi & 2) {
         if (!g.mask || ((uintptr_t)g.mask & 15) || g.mask_ld % 8 || g.mask_img_stride != cells * g.mask_ld) return 1;
@@ -400,7 +428,7 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     const long long Kbytes = Kel * 2;
     if (Kbytes > 16384 || Kbytes * d->N >= (long long)G8_OOB) return 1;
     const int cus = h->num_cus > 0 ? h->num_cus : 256;
-    const int ntn = d->N / 256;
+    const int ntn = (d->N + 255) / 256;
     int mi = mi_force;
     if (mi < 2 || mi > 3) {                            // tile height by rounds x (rows + a fixed per-tile cost)
         double best = 0;
@@ -431,6 +459,12 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (epi & 1) { p.res = (const char*)g.res; p.res_bytes = (unsigned)(g.res_elems * 2); p.res_ld = g.res_ld; }
     if (epi & 2) { p.mask = (const char*)g.mask; p.mask_bytes = (unsigned)(g.mask_elems * 2); p.mask_ld = g.mask_ld; }
     p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
+    if (res_up) {
+        p.res_up = 1; p.Hres = g.Hres; p.Wres = g.Wres;
+        p.res_img_stride = (unsigned)g.res_img_stride;
+        p.rs_h = (float)g.Hres / (float)g.Hout;
+        p.rs_w = (float)g.Wres / (float)g.Wout;
+    }
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;

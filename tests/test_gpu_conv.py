@@ -316,6 +316,26 @@ def test_halo8_column_blocks_and_k_slices(pkg, handle, monkeypatch, levels, cin,
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("levels,cin,cout,res,B,grid,mi", [
+    ([(40, 67)], 512, 256, "up", 2, 0, 0),         # C3_reduced-like: lateral 1x1 + UpsampleLike(coarser level) + Add, non-integer ratio
+    ([(25, 42)], 1024, 256, "up", 3, 2, 2),        # C4_reduced-like on 2 workgroups
+    ([(33, 50)], 128, 512, "same", 2, 3, 3),       # branch2c + identity shortcut
+    ([(40, 67)], 512, 128, None, 2, 0, 0),         # res3 branch2a: N = 128, the tile's upper 128 columns multiply zeros
+    ([(17, 23)], 64, 128, "same", 3, 1, 2),
+])
+def test_gemm8_residual_forms_and_half_width(pkg, handle, monkeypatch, levels, cin, cout, res, B, grid, mi):
+    """Generation 5 epilogues: identity shortcut, the FPN lateral's upsampled residual (model/layers.py:89-98 through
+    RTN_CONV_RES_UPSAMPLE), and N = 128 layers on the 256-column tile."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_G8_MI", str(mi))
+    flags = (L.CONV_RES_SAME if res == "same" else 0) | (L.CONV_RES_UPSAMPLE if res == "up" else 0) | (0 if res == "up" else L.CONV_RELU)
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 1, 1, 0, flags, res, B=B, seed=140 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+    check(gots, wants, ld, n, "bf16")
+
+
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
