@@ -18,7 +18,11 @@ Stated tolerances, boxes in pixels of the canvas after RegressBoxes (x = anchor 
               Measured on MI355X (image 0 vs float64): round-1 kernels P3 0.62, P4 0.99, P5 1.41, P6 2.37, P7 2.18 px = 0.96 /
               0.69 / 0.57 / 0.46 / 0.25 % of the side, scores 9.6e-3; with the persistent kernels and the fused bottleneck blocks
               (another f32 summation order, same rounding points) 0.60 / 0.89 / 1.31 / 2.49 / 1.93 px = 1.01 / 0.69 / 0.60 / 0.46 /
-              0.25 %, scores 1.0e-2: the same noise, another realisation of it.
+              0.25 %, scores 1.0e-2: the same noise, another realisation of it; with K-sliced stage-5 layers 0.56 / 0.89 / 1.49 /
+              2.32 / 2.51 px.  Those bounds are against the FLOAT64 oracle (the truth).  The bf16-emulating torch oracle is a second
+              bf16 computation whose own distance from the truth is of the same size (printed as "yardstick"), so two bf16 results can
+              be 1.5 x further apart than either is from the truth: against it the bounds are 1.5 x the ones above (measured 0.62 /
+              1.28 / 2.19 / 2.28 / 3.31 px), and the engine may not be further from the truth than 1.5 x the yardstick + 0.25 px.
   ResNet-101  (configs[4], 1024x1024) bf16: within 1.5 x what torch-CPU's own bf16 emulation of that graph loses against float64
               (that random 101-layer network amplifies rounding 4 x more than the ResNet-50 one: 2.8 px / 4 % of the side on P3);
               fp8 plan (towers + backbone 3x3 + P3 in e4m3) against the FLOAT64 oracle: regression relative RMS <= 0.10, score
@@ -101,11 +105,19 @@ def test_r50_800x1333_batch8_bf16_against_both_oracles(pkg, r50_case):
     reg, cls = reg.cpu().numpy(), cls.cpu().numpy()
     assert reg.shape == (8, 200700, 4) and cls.shape == (8, 200700, 1)
     for b in c["picks"]:
-        for tag, (oreg, ocls) in (("float64 oracle", c["o64"][b]), ("bf16-emulating oracle", c["oemu"][b])):
+        # the float64 oracle is the truth: <= 2 px on P3-P5, <= 4 px on P6 / P7, <= 1.5 % of the anchor's side, scores <= 2e-2.
+        # The bf16-emulating oracle (torch CPU, every conv input / weight / output rounded to bf16) is a second bf16 computation with
+        # its own rounding noise of the same size (printed below as "yardstick"): against it the bound is 1.5 x the one above, and
+        # the engine may not be further from the truth than 1.5 x the yardstick is (+ 0.25 px).
+        yard, _ = drift_report("yardstick: bf16-emulating oracle of image %d vs float64 oracle" % b, c["oemu"][b][0], c["oemu"][b][1],
+                               c["o64"][b][0], c["o64"][b][1], c["canvas"])
+        for tag, (oreg, ocls), slack in (("float64 oracle", c["o64"][b], 1.0), ("bf16-emulating oracle", c["oemu"][b], 1.5)):
             rows, dcls = drift_report("bf16 image %d vs %s" % (b, tag), reg[b], cls[b], oreg, ocls, c["canvas"])
-            assert dcls <= 2e-2
-            for lv, dpx, dfrac, _ in rows:
-                assert dpx <= (2.0 if lv <= 5 else 4.0) and dfrac <= 1.5e-2, "P%d drifts %.3f px (%.3e of the anchor side)" % (lv, dpx, dfrac)
+            assert dcls <= 2e-2 * slack
+            for (lv, dpx, dfrac, _), (_, ypx, _, _) in zip(rows, yard):
+                assert dpx <= slack * (2.0 if lv <= 5 else 4.0) and dfrac <= slack * 1.5e-2, "P%d drifts %.3f px (%.3e of the anchor side)" % (lv, dpx, dfrac)
+                if slack == 1.0:
+                    assert dpx <= 1.5 * ypx + 0.25, "P%d: engine %.3f px from the truth, torch bf16 emulation %.3f px" % (lv, dpx, ypx)
     # the uint8 entry of the same pages (normalisation fused into the packer) is what a data loader hands over: same bits
     reg8, cls8 = eng.forward(c["u8"].cuda())
     torch.cuda.synchronize()
