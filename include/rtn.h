@@ -141,6 +141,8 @@ size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
 /* Which kernel generation the last convolution launch on this handle ran (1: 128-row register-staged, 2: 256-row LDS-DMA per tap,
  * 3: 256-row shared halo, 4: persistent 8-phase halo kernel).  For tests and profiles: proves which native path executed. */
 int rtn_debug_last_conv_impl(rtn_handle_t h);
+/* 1 when the last weight-gradient call of this handle ran the 3x3 halo kernel (csrc/rtn_wgrad_halo.hip), 0 for the general kernels */
+int rtn_debug_last_wgrad_impl(rtn_handle_t h);
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
 
 /* Two 1x1 convolutions that are ADDED, as one GEMM over the concatenated K: out = W1 . in + W2 . in2[stepped] + bias (+ the

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rtn_version": (C.c_char_p, []),
     "rtn_conv2d_workspace_bytes": (_SZ, [_P, C.POINTER(ConvDesc)]),
     "rtn_debug_last_conv_impl": (_I, [_P]),
+    "rtn_debug_last_wgrad_impl": (_I, [_P]),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),

@@ -49,6 +49,8 @@ struct WParams {
     WGroup g[RTN_MAX_GROUPS];
     float* dW;
     float* db;           // optional bias gradient (BiasAddGrad fused: column sums of dY), accumulated by the tile_k == 0 blocks
+    float* slab;         // not null: every pixel split stores its tile into slab[split][N][Ktot] (plain stores) and wgrad_finish adds the
+    float* bslab;        // splits in order into dW / db - no atomics, the same bits on every run; bslab[split][N] for the bias sums
     int db_n;            // valid bias entries
     const uint4* rowinfo;
     int ngroups, total_tiles, tiles_per_split, ntiles_k;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
                 float v = 0.f;
                 for (int rr = 0; rr < 16; ++rr) v += sb[(t + 16 * rr) * CE + j];
                 const int n = n0 + t * CE + j;
-                if (n < p.db_n) unsafeAtomicAdd(p.db + n, v);
+                if (n < p.db_n) { if (p.slab) p.bslab[(long long)split * p.N + n] = v; else unsafeAtomicAdd(p.db + n, v); }
             }
         }
     }
@@ -305,7 +307,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WParams p) {
 #pragma unroll 4
             for (int nl = 0; nl < WT; ++nl) {
                 const int n = n0 + wm * WT + nl;
-                if (n < p.N) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, S[nl * SP + lane]);
+                if (n < p.N) {
+                    if (p.slab) p.slab[((long long)split * p.N + n) * p.Ktot + kc] = S[nl * SP + lane];
+                    else unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, S[nl * SP + lane]);
+                }
             }
         }
     }
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             const int n = n0 + wm * 64 + 16 * i + lc;
-            if (lane < 16 && n < p.db_n) unsafeAtomicAdd(p.db + n, v);
+            if (lane < 16 && n < p.db_n) { if (p.slab) p.bslab[(long long)split * p.N + n] = v; else unsafeAtomicAdd(p.db + n, v); }
         }
     }
 #pragma unroll
@@ -515,7 +520,10 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wm * 64 + 16 * i + lr + r;
-                if (n < p.N && kc < p.Ktot) unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+                if (n < p.N && kc < p.Ktot) {
+                    if (p.slab) p.slab[((long long)split * p.N + n) * p.Ktot + kc] = acc[i][j][r];
+                    else unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+                }
             }
         }
 }
@@ -966,15 +974,74 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// Which general kernel runs a layer and how its pixels are split (shared by the launcher and the workspace size; sized for the 256 CUs
+// of an MI355X when there is no handle).
+struct WgradPlan {
+    bool dma, dma_small, xcd_map;
+    int CH;
+    long long tiles, out_tiles, nsplit, nsplit_used;
+    int tiles_per_split;
+};
+static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
+    WgradPlan w;
+    const int es = rtn_dtype_size(d->dtype);
+    const long long Ktot = (long long)d->KH * d->KW * d->Crun;
+    w.tiles = 0;
+    for (int i = 0; i < d->ngroups; ++i) w.tiles += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 63) / 64;
+    // bf16 layers with more than 128 filters and at least one 256-wide K tile: the 256 x 256 LDS-DMA kernel (RTN_WGRAD_DMA=0: off)
+    // Measured per layer (tools/profile_train.py, batch 16): -27 % on the head layers (5575 pixel tiles, 0.71 -> 0.52 ms) and
+    // -21 % on P3, but +25..40 % on the layers with ~1000 pixel tiles or fewer (res4/res5, C4/C5, P5, P6: short loops, and each
+    // workgroup ends with 128 accumulator registers of output), hence the pixel-count condition.
+    w.dma = es == 2 && d->N > 128 && Ktot >= 256 && w.tiles >= 2048;
+    if (const char* e = getenv("RTN_WGRAD_DMA")) {          // 0: never; 2: wherever the shape allows (tests, A/B)
+        const int v = atoi(e);
+        w.dma = v == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (w.dma && v != 0);
+    }
+    // the same staging on the 128 x 128 tile for the other bf16 layers with whole 128-wide tiles (RTN_WGRAD_DMA_SMALL=0: register-staged kernel)
+    w.dma_small = !w.dma && es == 2;                       // measured: train step 37.4 -> 36.8 ms against the register-staged kernel
+    if (const char* e = getenv("RTN_WGRAD_DMA_SMALL")) w.dma_small = w.dma_small && atoi(e) != 0;
+    if (const char* e = getenv("RTN_WGRAD_DMA")) { if (atoi(e) == 0) w.dma_small = false; }
+    w.CH = w.dma ? 256 : (es == 2 ? 128 : 64);
+    const int ntn = (d->N + w.CH - 1) / w.CH;
+    const long long ntk = (Ktot + w.CH - 1) / w.CH;
+    w.out_tiles = (long long)ntn * ntk;
+    // Workgroup count: whole rounds of the resident slots (two 256-thread workgroups per CU), rounded DOWN - 1044 workgroups
+    // on 1024 slots cost a third round (training step 40.8 -> 38.8 ms).  RTN_WGRAD_BLOCKS overrides the target.
+    // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
+    // bound by the latency of its register-staged loads, not by MFMA work per byte.)
+    const long long slots = (long long)(cus > 0 ? cus : 256) * (w.dma ? 1 : 2);
+    long long target = slots * (w.dma_small ? 1 : 2);      // measured (RTN_WGRAD_BLOCKS sweep): one round for the 128 x 128 DMA kernel
+    if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
+    long long nsplit = target / w.out_tiles;
+    if (nsplit > w.tiles) nsplit = w.tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    w.xcd_map = nsplit >= 8 && getenv("RTN_WGRAD_XCD") == nullptr;
+    if (w.xcd_map) nsplit &= ~7ll;
+    w.tiles_per_split = (int)((w.tiles + nsplit - 1) / nsplit);
+    w.nsplit_used = (w.tiles + w.tiles_per_split - 1) / w.tiles_per_split;      // splits that own at least one pixel tile
+    w.nsplit = w.nsplit_used;
+    if (w.xcd_map && (w.nsplit & 7)) w.nsplit = (w.nsplit + 7) & ~7ll;          // the XCD map wants a multiple of 8: the extra splits are empty
+    return w;
+}
+
+// workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel
+// (rtn_wgrad_halo.hip) uses the same bytes for its own slabs
 extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
-    if (!d || d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS) return 0;
-    long long tiles = 0;
-    for (int i = 0; i < d->ngroups; ++i) tiles += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 63) / 64;
-    return (size_t)tiles * 64 * sizeof(uint4);
+    if (!d || d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS || d->N < 1 || d->Crun < 1 || d->KH < 1 || d->KW < 1) return 0;
+    if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return 0;
+    const WgradPlan w = wgrad_plan(d, 256);
+    size_t table = ((size_t)w.tiles * 64 * sizeof(uint4) + 255) & ~(size_t)255;
+    if (rtn_env_int("RTN_WGRAD_SLAB", 1) != 0)
+        table += (size_t)w.nsplit_used * (size_t)d->N * ((size_t)d->KH * d->KW * d->Crun + 1) * sizeof(float);
+    const size_t halo = rtn_env_int("RTN_WGRAD_HALO", 0) != 0 ? rtn_wgrad_halo_workspace_bytes(d) : 0;
+    return table > halo ? table : halo;
 }
 
 static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes,
                         int mode = 0 /* 0: build the row-info table and run; 1: build it only; 2: run on a table built earlier */);
+
+extern "C" int rtn_debug_last_wgrad_impl(rtn_handle_t h) { return h ? h->last_wgrad_impl : RTN_EINVAL; }
 
 extern "C" int rtn_conv2d_wgrad(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, void* workspace, size_t workspace_bytes) {
     return wgrad_launch(h, d, dW, nullptr, 0, workspace, workspace_bytes);
@@ -1012,7 +1079,30 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     if (((uintptr_t)dW & 15) || ((uintptr_t)workspace & 15)) return rtn_fail(h, RTN_EINVAL, "wgrad: dW/workspace alignment");
     const long long pix_b = (long long)d->pix_stride * es;
     if (pix_b % 16 && (d->KW != 1 || (d->sx * pix_b) % 16 || (d->pad_l * pix_b) % 16)) return rtn_fail(h, RTN_EINVAL, "wgrad: unaligned taps");
-    if (workspace_bytes < rtn_conv2d_wgrad_workspace_bytes(d)) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, rtn_conv2d_wgrad_workspace_bytes(d));
+    {   // required: the row-info table; the slabs of the ordered reduction behind it are used when there is room (else float atomics)
+        long long t64 = 0;
+        for (int i = 0; i < d->ngroups; ++i) t64 += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 63) / 64;
+        const size_t need = (size_t)t64 * 64 * sizeof(uint4);
+        if (workspace_bytes < need) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, need);
+    }
+
+    // the stride-1 3x3 layers with whole 128-channel blocks on rtn_wgrad_halo.hip (RTN_WGRAD_HALO=1; off by default: measured 0.31 ms
+    // per head layer against 0.29 ms for the general kernel, see that file)
+    if (rtn_env_int("RTN_WGRAD_HALO", 0) != 0 && rtn_wgrad_halo_workspace_bytes(d) > 0) {
+        bool ok = true;
+        for (int i = 0; i < d->ngroups && ok; ++i) {
+            const rtn_conv_group_t& s = d->g[i];
+            const long long cells = (long long)s.Hout * s.Wout, M = cells * d->batch;
+            ok = s.in && s.out && !((uintptr_t)s.in & 15) && !((uintptr_t)s.out & 15) && s.in_elems >= M * d->Crun &&
+                 s.out_elems >= (M - 1) * d->out_ld + d->N;
+        }
+        if (ok) {
+            if (mode == 1) return RTN_OK;              // nothing to prepare
+            const int rc = rtn_wgrad_halo_try(h, d, dW, db, db_n, workspace, workspace_bytes);
+            if (rc == RTN_OK) h->last_wgrad_impl = 1;
+            if (rc <= 0) return rc;
+        }
+    }
 
     WParams p;
     memset(&p, 0, sizeof(p));
@@ -1043,20 +1133,9 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         tiles += (cells * d->batch + 63) / 64;
     }
     if (tiles > (1 << 24)) return rtn_fail(h, RTN_EINVAL, "wgrad: too many pixels");
-    // bf16 layers with more than 128 filters and at least one 256-wide K tile: the 256 x 256 LDS-DMA kernel (RTN_WGRAD_DMA=0: off)
-    // Measured per layer (tools/profile_train.py, batch 16): -27 % on the head layers (5575 pixel tiles, 0.71 -> 0.52 ms) and
-    // -21 % on P3, but +25..40 % on the layers with ~1000 pixel tiles or fewer (res4/res5, C4/C5, P5, P6: short loops, and each
-    // workgroup ends with 128 accumulator registers of atomics), hence the pixel-count condition.
-    bool dma = es == 2 && d->N > 128 && Ktot >= 256 && tiles >= 2048;
-    if (const char* e = getenv("RTN_WGRAD_DMA")) {          // 0: never; 2: wherever the shape allows (tests, A/B)
-        const int v = atoi(e);
-        dma = v == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (dma && v != 0);
-    }
-    // the same staging on the 128 x 128 tile for the other bf16 layers with whole 128-wide tiles (RTN_WGRAD_DMA_SMALL=0: register-staged kernel)
-    bool dma_small = !dma && es == 2;                      // measured: train step 37.4 -> 36.8 ms against the register-staged kernel
-    if (const char* e = getenv("RTN_WGRAD_DMA_SMALL")) dma_small = dma_small && atoi(e) != 0;
-    if (const char* e = getenv("RTN_WGRAD_DMA")) { if (atoi(e) == 0) dma_small = false; }
-    const int CH = dma ? 256 : (es == 2 ? 128 : 64);
+    const WgradPlan w = wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256);
+    const bool dma = w.dma, dma_small = w.dma_small;
+    const int CH = w.CH;
     p.dW = dW;
     p.db = db;
     p.db_n = db_n;
@@ -1072,34 +1151,26 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.pix_stride_b = (int)pix_b;
     p.sy = d->sy; p.sx = d->sx; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.dy_ld_b = d->out_ld * es;
-    const int ntn = (d->N + CH - 1) / CH;
     p.ntiles_k = (int)((Ktot + CH - 1) / CH);
-    const long long out_tiles = (long long)ntn * p.ntiles_k;
-    // Workgroup count: whole rounds of the resident slots (two 256-thread workgroups per CU), rounded DOWN - 1044 workgroups
-    // on 1024 slots cost a third round (training step 40.8 -> 38.8 ms).  RTN_WGRAD_BLOCKS overrides the target.
-    // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
-    // bound by the latency of its register-staged loads, not by MFMA work per byte.)
-    const long long slots = (long long)(h->num_cus > 0 ? h->num_cus : 256) * (dma ? 1 : 2);
-    long long target = slots * (dma_small ? 1 : 2);      // measured (RTN_WGRAD_BLOCKS sweep): one round for the 128 x 128 DMA kernel (fewer atomics)
-    if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
-    long long nsplit = target / out_tiles;
-    if (nsplit > tiles) nsplit = tiles;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 65535) nsplit = 65535;
-    bool xcd_map = nsplit >= 8 && getenv("RTN_WGRAD_XCD") == nullptr;
-    if (xcd_map) nsplit &= ~7ll;
-    p.tiles_per_split = (int)((tiles + nsplit - 1) / nsplit);
-    nsplit = (tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    const long long out_tiles = w.out_tiles;
+    long long nsplit = w.nsplit;
+    const bool xcd_map = w.xcd_map;
+    p.tiles_per_split = w.tiles_per_split;
+    // ordered reduction: slabs behind the row-info table when the workspace has room for them (rtn_conv2d_wgrad_workspace_bytes asks
+    // for it); otherwise float atomics into dW (the same values, run-to-run differences in the last bits)
+    const size_t table_b = ((size_t)tiles * 64 * sizeof(uint4) + 255) & ~(size_t)255;
+    const size_t slab_b = (size_t)w.nsplit_used * (size_t)d->N * ((size_t)Ktot + 1) * sizeof(float);
+    const bool use_slab = mode != 1 && rtn_env_int("RTN_WGRAD_SLAB", 1) != 0 && workspace_bytes >= table_b + slab_b && (((long long)d->N * Ktot) % 4 == 0);
+    if (use_slab) {
+        p.slab = (float*)((char*)workspace + table_b);
+        p.bslab = p.slab + (size_t)w.nsplit_used * d->N * Ktot;
+    }
 
     if (mode != 2) {         // the table depends on the layer's geometry and the dY / X base offsets only: a caller may build it once
         if (es == 2) hipLaunchKernelGGL((wgrad_rowinfo_kernel<2>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
         else         hipLaunchKernelGGL((wgrad_rowinfo_kernel<4>), dim3(grid_for(tiles * 64)), dim3(256), 0, h->stream, p, (uint4*)workspace);
         RTN_CHECK_LAUNCH(h, "wgrad_rowinfo_kernel");
         if (mode == 1) return RTN_OK;
-    }
-    if (xcd_map && (nsplit & 7)) {              // the recomputed split count must stay a multiple of 8 for the XCD map
-        const long long up = (nsplit + 7) & ~7ll;    // extra splits are empty (tlo >= thi) and return at once
-        nsplit = up;
     }
     p.out_tiles = (int)out_tiles;
     p.xcd_map = xcd_map ? 1 : 0;
@@ -1109,6 +1180,8 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
+    h->last_wgrad_impl = 0;
+    if (use_slab) return rtn_wgrad_finish(h, dW, p.slab, (int)w.nsplit_used, (long long)d->N * Ktot, db, p.bslab, d->N, db ? db_n : 0);
     return RTN_OK;
 }
 

@@ -11,7 +11,9 @@ struct rtn_ctx {
     hipStream_t stream;
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
     int num_cus;
-    int last_conv_impl;     // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
+    int last_conv_impl;
+         // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
+    int last_wgrad_impl;          // 1 = rtn_wgrad_halo.hip, 0 = the general kernels (rtn_debug_last_wgrad_impl)
     char err[512];
 };
 
@@ -46,6 +48,9 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 int rtn_env_int(const char* name, int dflt);
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
                        long long ws_cap, size_t* query, int ksplit_force);
+size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);
+int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n);
+int rtn_wgrad_halo_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);
 int rtn_conv_ksplit_finish(rtn_handle_t h, const float* slab, int S, long long M, int N, int ld, const float* bias, int relu, void* out,
                            int out_ld);
 

@@ -241,6 +241,118 @@ def test_dgrad_on_the_persistent_kernels(pkg, handle, monkeypatch, impl, levels,
         assert err <= tol(dtype) * max(1.0, float(want.abs().max())), "dgrad err %.3e" % err
 
 
+@pytest.mark.parametrize("levels,cin,cout,B", [
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 4),     # head tower: five levels, 12 output tiles, stages cross levels
+    ([(25, 42)], 256, 256, 2),                # P5 / res4 branch2b-like
+    ([(40, 67)], 128, 128, 3),                # res3 branch2b: 3 output tiles, many pixel splits
+    ([(13, 21)], 512, 512, 3),                # res5 branch2b: 48 output tiles, more than one XCD's CUs
+    ([(7, 300)], 128, 256, 1),                # image rows much longer than a 62-pixel stage
+])
+def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
+    """csrc/rtn_wgrad_halo.hip: weight (+ bias) gradient of the stride-1 3x3 layers with one staged pixel image per kernel row, pixel
+    splits summed in order from slabs.  Against float64 autograd on the bf16-rounded operands, against the general kernel
+    (RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (no atomics)."""
+    L = pkg._lib
+    dtype = "bf16"
+    tdt, code = DT[dtype]
+    g = torch.Generator().manual_seed(500 + cin + cout)
+    w = q(torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(9 * cin), dtype).requires_grad_(True)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = 1
+    d.out_ld = cout
+    keep, want, wantb = [], 0, 0
+    for gi, (H, W) in enumerate(levels):
+        x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+        dy = q(torch.randn(B, H, W, cout, generator=g, dtype=torch.float64), dtype)
+        y = fwd_ref(x, w, 1, 1, 1, H, W)
+        want = want + torch.autograd.grad(y, w, dy)[0]
+        wantb = wantb + dy.sum(dim=(0, 1, 2))
+        xd, dyd = x.to(tdt).to(DEV).contiguous(), dy.to(tdt).to(DEV).contiguous()
+        keep += [xd, dyd]
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems, grp.out_img_stride = dyd.data_ptr(), dyd.numel(), H * W * cout
+        d.g[gi] = grp
+    wantm = want.permute(3, 0, 1, 2).reshape(cout, -1)
+
+    def run(halo):
+        monkeypatch.setenv("RTN_WGRAD_HALO", "1" if halo else "0")
+        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dW = torch.full((cout, 9 * cin), 0.5, dtype=torch.float32, device=DEV)
+        db = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
+        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        torch.cuda.synchronize()
+        assert L.lib.rtn_debug_last_wgrad_impl(handle.raw) == (1 if halo else 0)
+        return dW.cpu(), db.cpu()
+
+    dW1, db1 = run(True)
+    scale = max(1.0, float(wantm.abs().max()))
+    err = float((dW1.double() - 0.5 - wantm).abs().max())
+    assert err <= tol(dtype) * scale, "wgrad err %.3e scale %.2f" % (err, scale)
+    errb = float((db1.double() - 0.25 - wantb).abs().max())
+    assert errb <= tol(dtype) * max(1.0, float(wantb.abs().max())), "bias grad err %.3e" % errb
+    dW2, db2 = run(True)
+    assert torch.equal(dW1, dW2) and torch.equal(db1, db2)                 # ordered sums: the same bits every time
+    dW0, db0 = run(False)                                                   # the general kernel (float atomics): same values, other order
+    assert float((dW0 - dW1).abs().max()) <= 1e-3 * scale
+    assert float((db0 - db1).abs().max()) <= 1e-3 * max(1.0, float(wantb.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("H,W,cin,cout,k,B,env", [
+    (40, 67, 256, 64, 1, 4, {}),                           # 128 x 128 kernel, many pixel splits (XCD map)
+    (40, 67, 64, 64, 3, 4, {}),                            # 3x3, taps
+    (50, 84, 256, 256, 3, 2, {"RTN_WGRAD_DMA": "2"}),      # the 256 x 256 LDS-DMA kernel
+    (25, 42, 512, 2048, 1, 2, {}),                         # many output tiles, few splits
+])
+def test_wgrad_general_kernels_repeat_bit_for_bit(pkg, handle, monkeypatch, dtype, H, W, cin, cout, k, B, env):
+    """The pixel splits of the general weight-gradient kernels go to slabs behind the row-info table and are added in split order:
+    no float atomics, two runs give the same bits (and the same values as the float-atomic path, RTN_WGRAD_SLAB=0)."""
+    L = pkg._lib
+    tdt, code = DT[dtype]
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, cin, generator=g).to(tdt).to(DEV).contiguous()
+    dy = torch.randn(B, H, W, cout, generator=g).to(tdt).to(DEV).contiguous()
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, B, code
+    d.w_rows, d.N, d.KH, d.KW = cout, cout, k, k
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = k // 2
+    d.out_ld = cout
+    grp = L.ConvGroup()
+    grp.in_, grp.in_elems, grp.in_img_stride, grp.in_row_stride = x.data_ptr(), x.numel(), H * W * cin, W * cin
+    grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+    grp.out, grp.out_elems, grp.out_img_stride = dy.data_ptr(), dy.numel(), H * W * cout
+    d.g[0] = grp
+
+    def run(slab):
+        monkeypatch.setenv("RTN_WGRAD_SLAB", "1" if slab else "0")
+        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dW = torch.full((cout, k * k * cin), 0.5, dtype=torch.float32, device=DEV)
+        db = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
+        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        torch.cuda.synchronize()
+        return dW.cpu(), db.cpu()
+
+    w1, b1 = run(True)
+    w2, b2 = run(True)
+    assert torch.equal(w1, w2) and torch.equal(b1, b2)
+    w0, b0 = run(False)
+    scale = max(1.0, float(w0.abs().max()))
+    assert float((w0 - w1).abs().max()) <= 1e-4 * scale and float((b0 - b1).abs().max()) <= 1e-4 * max(1.0, float(b0.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wgrad_grouped_levels_and_padded_head_output(pkg, handle, dtype):
     """Shared head weights: one wgrad launch over five pyramid levels; dY of the 36-channel output padded to 64."""

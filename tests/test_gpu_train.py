@@ -167,3 +167,27 @@ def test_trainer_follows_engine_load_state(pkg):
     eng.load_state(st_a)
     with pytest.raises(RuntimeError):
         tr.optimizer_step()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_steps_repeat_bit_for_bit(pkg, dtype):
+    """No float atomics in the step: every weight-gradient kernel stores its pixel splits into slabs and adds them in split order
+    (csrc/rtn_backward.hip, rtn_wgrad_halo.hip).  Two trainers started from the same state and fed the same two batches end with
+    the same bits in the flat gradient, the Adam moments and the master weights; the wgrad lanes run on side streams meanwhile."""
+    E, Wt, T = mods(pkg)
+    state = Wt.init_state("resnet50", 1, 9, seed=3, randomize_bn=True, cls_bias=-2.0, tame=True)
+    batches = [make_batch(2, seed=31), make_batch(2, seed=32)]
+    results = []
+    for run in range(2):
+        eng = E.Engine("resnet50", 1, 9, dtype=dtype)
+        eng.load_state(state)
+        tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001)
+        losses = []
+        for x, reg_t, lab_t in batches:
+            losses.append(tr.train_on_batch(torch.as_tensor(x).cuda(), torch.as_tensor(reg_t).cuda(), torch.as_tensor(lab_t).cuda()))
+        torch.cuda.synchronize()
+        results.append((losses, tr.grad.clone(), tr.master.clone(), tr.m.clone(), tr.v.clone()))
+    a, b = results
+    assert a[0] == b[0], (a[0], b[0])
+    for i, what in ((1, "gradient"), (2, "master weights"), (3, "first moment"), (4, "second moment")):
+        assert torch.equal(a[i], b[i]), "%s differs between two identical runs (max %.3e)" % (what, float((a[i] - b[i]).abs().max()))
