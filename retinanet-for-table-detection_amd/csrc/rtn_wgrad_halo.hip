@@ -261,24 +261,47 @@ __global__ __launch_bounds__(WH_THREADS, 2) void conv_wgrad_halo_kernel(const WH
     }
 }
 
-// dW[n][k] += slab[0][n][k] + slab[1][n][k] + ... (in that order); db[n] += the same over bslab
-__global__ __launch_bounds__(256) void wgrad_halo_finish_kernel(float* __restrict__ dW, const float* __restrict__ slab, int S, long long NK,
-                                                                float* __restrict__ db, const float* __restrict__ bslab, int N, int db_n) {
-    const long long nk4 = NK / 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nk4; i += (long long)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(slab)[i];
-        for (int s = 1; s < S; ++s) {
-            const float4 a = reinterpret_cast<const float4*>(slab + (size_t)s * NK)[i];
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+// dW[i] += slab[0][i] + slab[1][i] + ... + slab[S-1][i] with a FIXED association: the S splits are cut into SL consecutive ranges, every
+// range is summed in order by one "split lane" (SL lanes x 256 / SL float4 columns per block), and the SL partial sums are added in
+// lane order.  Same bits on every run; SL only spreads the loads of a many-split, few-weights layer (res2: 256 splits x 16 K weights)
+// over enough threads.  Blocks past `main_blocks` do the same for the bias slabs (scalar columns).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dW, const float* __restrict__ slab, int S, long long NK,
+                                                           float* __restrict__ db, const float* __restrict__ bslab, int N, int db_n, int main_blocks) {
+    constexpr int CB = 256 / SL;
+    __shared__ float4 part[SL][CB];
+    const int c = threadIdx.x % CB, sl = threadIdx.x / CB;
+    const int per = (S + SL - 1) / SL;
+    const int s0 = sl * per, s1 = s0 + per < S ? s0 + per : S;
+    if ((int)blockIdx.x < main_blocks) {
+        const long long i = (long long)blockIdx.x * CB + c;          // float4 column
+        const bool live = i < NK / 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+            for (int s = s0; s < s1; ++s) {
+                const float4 a = reinterpret_cast<const float4*>(slab + (size_t)s * NK)[i];
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+        part[sl][c] = v;
+        __syncthreads();
+        if (sl == 0 && live) {
+#pragma unroll
+            for (int l = 1; l < SL; ++l) { const float4 a = part[l][c]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            float4 w = reinterpret_cast<float4*>(dW)[i];
+            w.x += v.x; w.y += v.y; w.z += v.z; w.w += v.w;
+            reinterpret_cast<float4*>(dW)[i] = w;
         }
-        float4 w = reinterpret_cast<float4*>(dW)[i];
-        w.x += v.x; w.y += v.y; w.z += v.z; w.w += v.w;
-        reinterpret_cast<float4*>(dW)[i] = w;
-    }
-    if (db && blockIdx.x == 0) {
-        for (int n = threadIdx.x; n < db_n; n += blockDim.x) {
-            float v = bslab[n];
-            for (int s = 1; s < S; ++s) v += bslab[(size_t)s * N + n];
+    } else {
+        const int n = ((int)blockIdx.x - main_blocks) * CB + c;
+        const bool live = n < db_n;
+        float v = 0.f;
+        if (live)
+            for (int s = s0; s < s1; ++s) v += bslab[(size_t)s * N + n];
+        part[sl][c].x = v;
+        __syncthreads();
+        if (sl == 0 && live) {
+#pragma unroll
+            for (int l = 1; l < SL; ++l) v += part[l][c].x;
             db[n] += v;
         }
     }
@@ -326,10 +349,16 @@ bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
 // of the pixel splits of every weight-gradient kernel
 int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n) {
     if (!dW || !slab || S < 1 || NK < 4 || NK % 4) return rtn_fail(h, RTN_EINVAL, "wgrad finish: bad argument");
-    long long fg = (NK / 4 + 255) / 256;
-    if (fg > 2048) fg = 2048;
-    hipLaunchKernelGGL(wgrad_halo_finish_kernel, dim3((unsigned)fg), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, db ? db_n : 0);
-    RTN_CHECK_LAUNCH(h, "wgrad_halo_finish_kernel");
+    const int nb = db ? db_n : 0;
+#define RTN_WF(SL_)                                                                                               \
+    do {                                                                                                          \
+        const long long mb = (NK / 4 + 256 / SL_ - 1) / (256 / SL_);                                              \
+        const long long bb = (nb + 256 / SL_ - 1) / (256 / SL_);                                                  \
+        hipLaunchKernelGGL((wgrad_finish_kernel<SL_>), dim3((unsigned)(mb + bb)), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, nb, (int)mb); \
+    } while (0)
+    if (S >= 64) RTN_WF(16); else if (S >= 8) RTN_WF(4); else RTN_WF(1);
+#undef RTN_WF
+    RTN_CHECK_LAUNCH(h, "wgrad_finish_kernel");
     return RTN_OK;
 }
 
@@ -394,11 +423,5 @@ int rtn_wgrad_halo_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, floa
     const unsigned grid = (unsigned)(p.ntiles * ((S + 7) / 8) * 8);
     hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3(grid), dim3(WH_THREADS), WH_LDS, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_halo_kernel");
-    const long long NK = (long long)d->N * Ktot;
-    long long fg = (NK / 4 + 255) / 256;
-    if (fg > 2048) fg = 2048;
-    hipLaunchKernelGGL(wgrad_halo_finish_kernel, dim3((unsigned)fg), dim3(256), 0, h->stream, dW, (const float*)p.slab, S_used, NK, db,
-                       (const float*)p.bslab, d->N, db ? db_n : 0);
-    RTN_CHECK_LAUNCH(h, "wgrad_halo_finish_kernel");
-    return RTN_OK;
+    return rtn_wgrad_finish(h, dW, p.slab, S_used, (long long)d->N * Ktot, db, p.bslab, d->N, db ? db_n : 0);
 }
