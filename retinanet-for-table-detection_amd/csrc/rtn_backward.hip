@@ -1025,6 +1025,17 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     return w;
 }
 
+// rtn_wgrad_halo.hip (stride-1 3x3 layers with whole 128-channel blocks) against the general kernels, measured per shape at batch 8
+// (tools/ab_wgrad.py): res4 branch2b / P4 0.075 vs 0.110 ms, res3 branch2b 0.067 vs 0.082, but head towers 0.302 vs 0.284, P3 0.230 vs
+// 0.230, res5 branch2b 0.091 vs 0.086.  So it takes the layers the 256 x 256 LDS-DMA kernel does not, from ~25 k pixels on.
+// RTN_WGRAD_HALO=1: wherever the shape allows (tests, A/B), 0: never.
+static bool wgrad_takes_halo(const rtn_conv_desc_t* d, const WgradPlan& w) {
+    const int knob = rtn_env_int("RTN_WGRAD_HALO", -1);
+    if (knob == 0 || rtn_wgrad_halo_workspace_bytes(d) == 0) return false;
+    if (knob > 0) return true;
+    return !w.dma && w.tiles >= 400;
+}
+
 // workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel
 // (rtn_wgrad_halo.hip) uses the same bytes for its own slabs
 extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
@@ -1034,7 +1045,7 @@ extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
     size_t table = ((size_t)w.tiles * 64 * sizeof(uint4) + 255) & ~(size_t)255;
     if (rtn_env_int("RTN_WGRAD_SLAB", 1) != 0)
         table += (size_t)w.nsplit_used * (size_t)d->N * ((size_t)d->KH * d->KW * d->Crun + 1) * sizeof(float);
-    const size_t halo = rtn_env_int("RTN_WGRAD_HALO", 0) != 0 ? rtn_wgrad_halo_workspace_bytes(d) : 0;
+    const size_t halo = wgrad_takes_halo(d, w) ? rtn_wgrad_halo_workspace_bytes(d) : 0;
     return table > halo ? table : halo;
 }
 
@@ -1086,9 +1097,8 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         if (workspace_bytes < need) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, need);
     }
 
-    // the stride-1 3x3 layers with whole 128-channel blocks on rtn_wgrad_halo.hip (RTN_WGRAD_HALO=1; off by default: measured 0.31 ms
-    // per head layer against 0.29 ms for the general kernel, see that file)
-    if (rtn_env_int("RTN_WGRAD_HALO", 0) != 0 && rtn_wgrad_halo_workspace_bytes(d) > 0) {
+    // the stride-1 3x3 layers with whole 128-channel blocks that rtn_wgrad_halo.hip runs faster (wgrad_takes_halo)
+    if (wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
         bool ok = true;
         for (int i = 0; i < d->ngroups && ok; ++i) {
             const rtn_conv_group_t& s = d->g[i];
