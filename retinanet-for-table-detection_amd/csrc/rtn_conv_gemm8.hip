@@ -370,9 +370,9 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     const bool res_up = d->flags & RTN_CONV_RES_UPSAMPLE;
     const int epi = ((d->flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE)) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
     if (epi && s2) return 1;
-    // N = 128: half of the 256-column tile multiplies zeros (weight rows past w_rows come from the descriptor's range check); only
-    // worth it where the layer is bound by its pixel traffic (RTN_CONV_G8_N128, A/B)
-    const bool n128 = d->N == 128 && (forced || rtn_env_int("RTN_CONV_G8_N128", 0) != 0);
+    // N = 128: half of the 256-column tile multiplies zeros (weight rows past w_rows come from the descriptor's range check).  The
+    // layers this is for are bound by their pixel traffic: res3 branch2a in the step's sequence 0.063 -> 0.055 ms (RTN_CONV_G8_N128=0: off)
+    const bool n128 = d->N == 128 && (forced || rtn_env_int("RTN_CONV_G8_N128", 1) != 0);
     if (!n128 && (d->N < 256 || d->N % 256)) return 1;
     if (d->N > 2048 || d->w_rows != d->N || d->out_ld % 8) return 1;
     if ((d->Crun * 2) % 128 || d->Crun <= 0 || d->pix_stride < d->Crun || (d->pix_stride * 2) % 16) return 1;

@@ -111,8 +111,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // (the data-gradient launches of the training step, see rtn_conv2d_dgrad): 16 bytes per lane and row, loaded one row fragment ahead.
 // SPLIT: the work items carry a column block and a K slice (see H8Params); accumulators start at zero, the bias is added by the
 // epilogue (S = 1) or by the finish kernel (S > 1).
-template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT>
+// NW: column fragments (16 channels) per wave.  8 = the 256-column tile above.  4 = a 128-column tile for the 65..128-channel layers
+// (res3 branch2b): wave tile 64 MI/4.. rows x 64 columns, a K step is TWO phases of {MI + 4 fragment reads | 4 MI MFMAs} (the same
+// reads-per-MFMA ratio as the wide tile), the B stage has two 64-row pieces, a lane ends up with 4 consecutive channels (8-byte stores).
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
+    static_assert(NW == 8 || (NW == 4 && EPI == 0 && !SPLIT), "the half-width instance has the plain bias / ReLU epilogue only");
+    constexpr int NBP = NW / 2;                        // 64-row pieces of a B stage
     constexpr int R = 64 * MI;                         // rows of a tile's halo image
     constexpr int TM = R - KW;                         // output rows per tile; halo rows 0 .. R - 2, row R - 1 = zeros
     constexpr unsigned ZERO_ROW = (unsigned)(R - 1) * 128u;
@@ -132,15 +137,16 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 
     // ---- B staging: piece d of this wave fills LDS positions P = 64 d + 8 wave + lr; position 128 wn' + 16 j + c holds weight
     // row 128 wn' + 8 c + j (the column permutation that makes the epilogue's stores contiguous)
-    unsigned wrow_off[4];
+    // (NW = 4: position 64 wn' + 16 j + c holds weight row 64 wn' + 4 c + j)
+    unsigned wrow_off[NBP];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < NBP; ++d) {
         const int P = d * 64 + wave * 8 + lr;
-        const int nrow = (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7);
+        const int nrow = NW == 8 ? (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7) : (P >> 6) * 64 + 4 * (P & 15) + ((P >> 4) & 3);
         wrow_off[d] = (unsigned)nrow * (unsigned)p.Kbytes + (unsigned)sc * 16u;
     }
-    // B fragment read address of this lane inside a stage (position 128 wn + 16 j + lrow: + j * 2048), k half 0; k half 1 = ^ 64
-    const unsigned b_lane = (unsigned)((wn * 128 + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
+    // B fragment read address of this lane inside a stage (position 16 NW wn + 16 j + lrow: + j * 2048), k half 0; k half 1 = ^ 64
+    const unsigned b_lane = (unsigned)((wn * (16 * NW) + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
 
     // ---- per-tile state ------------------------------------------------------------------------------------------------
     // staging cursor (the tile whose halos are being staged): its group, first row, halo rows of this lane
@@ -225,15 +231,17 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }
     };
 
-    f32x4 acc[MI][8];
+    f32x4 acc[MI][NW];
     float bias8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
     if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + wn * 128 + 8 * lrow);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + wn * 128 + 8 * lrow + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + wn * (16 * NW) + NW * lrow);
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        if (NW == 8) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + wn * 128 + 8 * lrow + 4);
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
     }
 
     // ---- work items.  Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), and neighbouring row tiles read each
@@ -271,11 +279,12 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     {
         const unsigned kc0 = cboff + (unsigned)((kh0 * KW * nchunk + cc0) * 128);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) stage_b(d, kc0, 0);
+        for (int d = 0; d < NBP; ++d) stage_b(d, kc0, 0);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) stage_b(d, kc0 + (unsigned)(nchunk * 128), 1);
+        for (int d = 0; d < NBP - 1; ++d) stage_b(d, kc0 + (unsigned)(nchunk * 128), 1);
     }
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (NW == 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
 
@@ -331,6 +340,28 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }                                                                                            \
         H8_MFMA(1)                                                                                   \
     }
+    // The half-width step: phase A = k half 0 + the LAST piece of step s+1's B tile, phase B = k half 1 + the FIRST piece of step
+    // s+2's (its ring slot was last read two phases ago), halo pieces of the next group in both phases of taps 0 and 1.
+#define H8_STEP4(KWI)                                                                                \
+    {                                                                                                \
+        const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
+        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
+        uint4 fa[MI], fb[4];                                                                         \
+        H8_LDA(KWI, 0) H8_LDB(KWI, 0, 0)                                                             \
+        stage_b(1, kc_n1, ((KWI) + 1) % 3);                                                          \
+        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);             \
+        H8_MFMA(0)                                                                                   \
+        H8_LDA(KWI, 1) H8_LDB(KWI, 1, 0)                                                             \
+        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
+        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);     \
+        {                                                                                            \
+            constexpr int na_ = (KWI) < 2 ? ((2 * (KWI) < MI) + (2 * (KWI) + 1 < MI)) : 0;           \
+            if (na_ == 2)      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
+            else if (na_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                      \
+            else               asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                      \
+        }                                                                                            \
+        H8_MFMA(0)                                                                                   \
+    }
     static_assert(KW == 3 && MI >= 2 && MI <= 4, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3, MI <= 4");
 
     const unsigned kw_stride = (unsigned)(nchunk * 128);           // K bytes between the taps of a kernel row
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = SPLIT ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
+            for (int j = 0; j < NW; ++j) acc[i][j] = SPLIT ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
         int kh = kh0, cc = cc0;
         int rt1 = rt, cb1 = cb, sl1 = sl;
         unsigned cboff1 = cboff;
@@ -356,9 +387,15 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             }
             const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
             const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
-            H8_STEP(0)
-            H8_STEP(1)
-            H8_STEP(2)
+            if constexpr (NW == 8) {
+                H8_STEP(0)
+                H8_STEP(1)
+                H8_STEP(2)
+            } else {
+                H8_STEP4(0)
+                H8_STEP4(1)
+                H8_STEP4(2)
+            }
             // next group: the other halo buffer
 #pragma unroll
             for (int kw = 0; kw < KW; ++kw)
@@ -370,7 +407,34 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         kh0 = kh; cc0 = cc;                            // the next item starts at the group the cursor already points to
         // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane (rows beyond TM / M go to an out-of-range
         // offset and are dropped)
-        if (SPLIT && p.S > 1) {
+        if constexpr (NW == 4) {
+            // 4 consecutive channels per lane and row: 8-byte stores
+            const H8Group& Gc = p.g[gi];
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
+            const int ncol = wn * 64 + 4 * lrow;
+            const bool col_ok = ncol < p.N;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    const int m = m0 + rloc;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[i][j][r];
+                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    u32x2 o;
+                    o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+                    const bool ok = col_ok && rloc < TM && m < Gc.M;
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, (int)off, 0, 0);
+                    asm volatile("s_nop 3" :: "v"(o.x), "v"(o.y));
+                }
+        } else if (SPLIT && p.S > 1) {
             // f32 partial sums of this K slice -> slab[sl][m][256 cb + channel], 2 x 16 B per lane and row
             const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((char*)p.slab + (size_t)sl * p.slab_slice_bytes), 0, (int)__builtin_amdgcn_readfirstlane((int)p.slab_slice_bytes), 0x00020000);
@@ -461,6 +525,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         // the staging cursor's halo rows already belong to the next item (switched in the last group); the pieces it issued for an
         // item past the end are zeros from out-of-range offsets
     }
+#undef H8_STEP4
 #undef H8_STEP
 #undef H8_MFMA
 #undef H8_LDB
@@ -484,8 +549,10 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
     const int epi = ((d->flags & RTN_CONV_RES_SAME) ? 1 : 0) | ((d->flags & RTN_CONV_RELU_MASK) ? 2 : 0);
     const int ncb = (d->N + 255) / 256;                // column blocks of 256 channels
-    if (d->N <= 128 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;   // weight rows past w_rows read as zeros (descriptor range)
+    if (d->N <= 64 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;    // weight rows past w_rows read as zeros (descriptor range)
     if (ncb > 1 && epi) return 1;
+    const bool half = d->N <= 128;                     // the 128-column instance (NW = 4): plain epilogue, no slices
+    if (half && (epi || (!forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0))) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * 2) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
@@ -501,7 +568,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     // Tile height (rows = 64 mi) and K slices by a cost model in microseconds: rounds of workgroups x K steps of an item (+ 5 for its
     // prologue / epilogue) x 1.53 us per 256-row step, + for S > 1 the finish launch and the slabs' round trip at 4 TB/s.
     // RTN_CONV_H8_MI / RTN_CONV_H8_KSPLIT pin them (A/B, tests).
-    const bool can_split = d->ngroups == 1 && epi == 0 && ksplit_force != 1 && (ws_cap > 0 || query);
+    const bool can_split = !half && d->ngroups == 1 && epi == 0 && ksplit_force != 1 && (ws_cap > 0 || query);
     const long long slab_ld = 256ll * ncb;
     int mi = 0, S = 1;
     {
@@ -606,9 +673,20 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP, SP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
+#define RTN_H8_LAUNCH4(M_)                                                                               \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, 0, false, 4>,     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 4>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
-        if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                     \
+        if (half) RTN_H8_LAUNCH4(M_);                                                                    \
+        else if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                \
         else if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0, false);      /* lockstep variant: A/B only */ \
         else if (epi == 0) RTN_H8_LAUNCH(M_, true, 0, false);                                            \
         else if (epi == 1) RTN_H8_LAUNCH(M_, true, 1, false);                                            \
@@ -617,6 +695,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
+#undef RTN_H8_LAUNCH4
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
     if (S > 1) return rtn_conv_ksplit_finish(h, ws, S, Mtot, d->N, (int)slab_ld, d->bias, p.relu, d->g[0].out, d->out_ld);

@@ -237,6 +237,9 @@ def test_tail_split(pkg, handle, monkeypatch, dtype, impl, levels, cin, cout, k,
     ([(25, 42), (13, 21)], 128, 200, True, 2, 1),   # two chunks per tap, N not a multiple of 16, ONE workgroup walks all 11 tiles
     ([(7, 300)], 256, 136, True, 1, 2),        # rows longer than a tile: tiles start and end inside an image row
     ([(3, 5)], 256, 256, True, 1, 0),          # a single, mostly empty tile
+    ([(40, 67)], 128, 128, True, 3, 3),        # res3 branch2b: the 128-column instance (wave tile 64 columns, two phases per K step)
+    ([(25, 42), (13, 21)], 256, 72, False, 2, 1),   # ... N = 72: second column half mostly empty, four chunks per tap, one workgroup
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 128, 96, True, 2, 0),      # ... grouped levels
 ])
 def test_persistent_8phase_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, relu, B, grid, stagger, mi):
     """Generation 4 (csrc/rtn_conv_halo8.hip): persistent 256 x 256 tiles on the staggered 8-phase schedule, LDS-DMA in flight
