@@ -294,7 +294,7 @@ def main():
         def op_flops(op):
             if op[0] == "bneck":             # branch2b (3x3, 64 -> 64) + branch2c (64 -> 256) [+ the next branch2a (256 -> 64)]
                 m = op[3]
-                return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + (256 * 64 if m["tail"] else 0))
+                return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + (256 * 64 if (m["tail"] or m.get("proj")) else 0))
             return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
         flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         ms_per_step = 1e3 * elapsed / args.steps
@@ -319,6 +319,8 @@ def main():
             if op[0] == "bneck":             # a_in + shortcut in, x_out (+ a_out) out, the three filters
                 m = op[3]
                 px = m["B"] * m["H"] * m["W"]
+                if m.get("proj"):            # a_in + the block input in, x_out out, branch2b + the K-concatenated [branch2c | branch1] filters
+                    return 2.0 * (px * (64 + 64 + 256) + 576 * 64 + 128 * 256)
                 return 2.0 * (px * (64 + 256 + 256 + (64 if m["tail"] else 0)) + 576 * 64 + 64 * 256 + (256 * 64 if m["tail"] else 0))
             return conv_bytes(op[1], BATCH) + ((BATCH * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
         bytes_step = sum(op_bytes(op) for op in conv_ops)

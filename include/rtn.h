@@ -188,6 +188,7 @@ int rtn_quantize_fp8(rtn_handle_t h, const void* src, int src_dtype, void* dst, 
  *   h1    = relu(conv3x3(a_in;  w2b) + b2b)                 branch2b + BN + ReLU   (3x3 'same', 64 -> 64)
  *   x_out = relu(conv1x1(h1;    w2c) + b2c + x_in)          branch2c + BN + Add + ReLU  (64 -> 256)
  *   a_out = relu(conv1x1(x_out; w2a) + b2a)                 the NEXT block's branch2a + BN + ReLU (256 -> 64); skipped if a_out is NULL
+ * (the projection-shortcut form of the stage's first block: see p_in / wproj below)
  * (keras_resnet bottleneck_2d as instantiated by model/defineModel.py:376-380; BN folded into w / b as for rtn_conv2d_fwd.)
  * h1 never reaches memory and x_out is read back by nobody: 0.68 GB of HBM traffic per block at batch 8 instead of 1.09 GB.
  * Tensors are dense NHWC bf16, weights [N][KH*KW*Cin] K-contiguous as for rtn_conv2d_fwd (no row padding needed), biases f32.
@@ -204,7 +205,13 @@ typedef struct {
     int32_t batch, H, W;
     int32_t mid;                               /* bottleneck channels: 64                  */
     int32_t dtype;                             /* RTN_BF16                                 */
-    int32_t reserved_;
+    int32_t w2c_ld;                            /* elements between rows of w2c / wproj; 0 = mid (dense)                */
+    /* The stage's FIRST block (res2a), whose shortcut is a projection (model/defineModel.py:376-380, keras_resnet
+     * bottleneck_2d with block == 0):  x_out = relu(conv1x1(h1; w2c) + conv1x1(p_in; wproj) + b2c)  with b2c = b2c + b1 summed by
+     * the caller and p_in the block input [batch][H][W][mid].  x_in is not read; a_out must be NULL.  With the K-concatenated
+     * filters of rtn_conv1x1_dual_fwd ([4*mid][mid + mid]): w2c = that matrix, wproj = w2c + mid elements, w2c_ld = 2 * mid. */
+    const void* p_in;  int64_t p_in_elems;
+    const void* wproj;
 } rtn_bottleneck_desc_t;
 int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d);
 

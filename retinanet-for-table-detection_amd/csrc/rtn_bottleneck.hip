@@ -40,6 +40,9 @@ struct BkParams {
     const char* w2b;        // [64][3*3*64] bf16, BN folded
     const char* w2c;        // [256][64]
     const char* w2a;        // [64][256] (next block), or nullptr
+    const char* pin;        // PROJ: [M][64] bf16, the block INPUT (pool1): the shortcut is wproj x pin, computed here
+    const char* wproj;      // PROJ: [256][64] rows w2c_ld elements apart (the K-concatenated [branch2c | branch1] filters: wproj = w2c + 64)
+    int w2c_ld;             // elements between rows of w2c / wproj (64, or 128 for the K-concatenated filters)
     const float* b2b;       // [64], [256], [64] f32 (folded BN shifts)
     const float* b2c;
     const float* b2a;
@@ -83,8 +86,12 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 
 #define BK_STORE_GUARD(V) asm volatile("s_nop %4" :: "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "n"(RTN_BK_STORE_NOPS));
 #endif
 
-template <bool TAIL, int BK_THREADS, bool ROWPP>
+// PROJ: the stage's FIRST block (res2a).  Its shortcut is not the block input but branch1 = conv1x1(block input; wproj): four more
+// weight images sit where TAIL keeps the next branch2a's, the two 16-byte fragments of the input pixel (64 channels) are loaded once
+// per strip, and every output chunk gets 16 more MFMAs instead of 4 shortcut loads.  b2c then holds b2c + b1.
+template <bool TAIL, int BK_THREADS, bool ROWPP, bool PROJ = false>
 __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_kernel(const BkParams p) {
+    static_assert(!(TAIL && PROJ), "the 17 weight images hold either the next branch2a or the projection shortcut");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -97,8 +104,9 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
         for (int im = 0; im < 17 && t < 512; ++im) {
             const char* g = nullptr;
             if (im < 9)       g = p.w2b + ((long long)src * 576 + im * 64) * 2 + chunk * 16;
-            else if (im < 13) g = p.w2c + ((long long)((im - 9) * 64 + src) * 64) * 2 + chunk * 16;
+            else if (im < 13) g = p.w2c + ((long long)((im - 9) * 64 + src) * p.w2c_ld) * 2 + chunk * 16;
             else if (TAIL)    g = p.w2a + ((long long)src * 256 + (im - 13) * 64) * 2 + chunk * 16;
+            else if (PROJ)    g = p.wproj + ((long long)((im - 13) * 64 + src) * p.w2c_ld) * 2 + chunk * 16;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (g) v = *reinterpret_cast<const uint4*>(g);
             *reinterpret_cast<uint4*>(lds + im * IMG + rho * 128 + slot * 16) = v;
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.ain, 0, p.M * 128, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.xin, 0, p.M * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(PROJ ? p.pin : p.xin), 0, PROJ ? p.M * 128 : p.M * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.xout, 0, p.M * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t n_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? p.aout : p.xout), 0, TAIL ? p.M * 128 : 0, 0x00020000);
 
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 BK_MFMA(acc1[f_][1], wf_, SRC[kw_][ks_][1]);                                         \
             }
 #define BK_LOAD_RES(GI, G, DST)                                                                      \
+    if (!PROJ)                                                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
         _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
             const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((p.dbg & 2) ? BK_OOB : G.xoff[u_]), (GI) * 128 + s_ * 64, 0); \
@@ -199,6 +208,16 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
         for (int f = 0; f < 4; ++f) {
             const f32x4 bv = BK_BIAS(0, f);
             acc1[f][0] = bv; acc1[f][1] = bv;
+        }
+        uint4 pfrag[2][2];          // PROJ: [k half][u] the block input at this strip's pixels (B operand of the projection shortcut)
+        if (PROJ) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)gc.pbase[u], ks * 64, 0);
+                    pfrag[ks][u] = make_uint4(v.x, v.y, v.z, v.w);
+                }
         }
         {
             uint4 row1[3][2][2];
@@ -259,13 +278,23 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                     BK_MFMA(acc2[f][0], wf, h1[ks][0]);
                     BK_MFMA(acc2[f][1], wf, h1[ks][1]);
                 }
+            if (PROJ) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const uint4 wf = BK_WFRAG(W2A_OFF + g * IMG, f, ks);
+                        BK_MFMA(acc2[f][0], wf, pfrag[ks][0]);
+                        BK_MFMA(acc2[f][1], wf, pfrag[ks][1]);
+                    }
+            }
             uint4 xo[2][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const f32x4 lo = acc2[2 * s][u], hi = acc2[2 * s + 1][u];
-                    const uint4 r = res[s][u];
+                    const uint4 r = PROJ ? make_uint4(0u, 0u, 0u, 0u) : res[s][u];
                     const uint4 o = make_uint4(pack2(relu(lo[0] + bf_lo(r.x)), relu(lo[1] + bf_hi(r.x))),
                                                pack2(relu(lo[2] + bf_lo(r.y)), relu(lo[3] + bf_hi(r.y))),
                                                pack2(relu(hi[0] + bf_lo(r.z)), relu(hi[1] + bf_hi(r.z))),
@@ -334,19 +363,25 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     if (d->batch < 1 || d->H < 1 || d->W < 1) return rtn_fail(h, RTN_EINVAL, "bottleneck64: empty extent");
     const long long M = (long long)d->batch * d->H * d->W;
     if (M >= (1ll << 22)) return rtn_fail(h, RTN_EINVAL, "bottleneck64: %lld pixels exceed the 4 Mi-pixel (2 GiB tensor) range", M);
-    const void* need[] = {d->a_in, d->x_in, d->x_out, d->w2b, d->w2c, d->b2b, d->b2c};
+    const bool proj = d->wproj != nullptr;
+    const void* need[] = {d->a_in, proj ? d->p_in : d->x_in, d->x_out, d->w2b, d->w2c, d->b2b, d->b2c};
     for (const void* q : need)
         if (!q || ((uintptr_t)q & 15)) return rtn_fail(h, RTN_EINVAL, "bottleneck64: null / misaligned pointer");
     const bool tail = d->a_out != nullptr;
+    const int w2c_ld = d->w2c_ld > 0 ? d->w2c_ld : 64;
+    if (w2c_ld < 64 || w2c_ld % 8) return rtn_fail(h, RTN_EINVAL, "bottleneck64: w2c_ld %d", d->w2c_ld);
+    if (proj && (tail || ((uintptr_t)d->wproj & 15) || d->p_in_elems < M * 64))
+        return rtn_fail(h, RTN_EINVAL, "bottleneck64: the projection-shortcut form takes p_in [M][64], an aligned wproj and no a_out");
     if (tail && (!d->w2a || !d->b2a || ((uintptr_t)d->a_out & 15) || ((uintptr_t)d->w2a & 15) || ((uintptr_t)d->b2a & 15)))
         return rtn_fail(h, RTN_EINVAL, "bottleneck64: a_out needs aligned w2a / b2a");
-    if (d->a_in_elems < M * 64 || d->x_in_elems < M * 256 || d->x_out_elems < M * 256 || (tail && d->a_out_elems < M * 64))
+    if (d->a_in_elems < M * 64 || (!proj && d->x_in_elems < M * 256) || d->x_out_elems < M * 256 || (tail && d->a_out_elems < M * 64))
         return rtn_fail(h, RTN_EBOUNDS, "bottleneck64: a tensor is smaller than batch x H x W x channels");
-    if (d->x_out == d->x_in || d->x_out == d->a_in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the output may not alias an input (taps of neighbouring strips)");
+    if ((!proj && d->x_out == d->x_in) || d->x_out == d->a_in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the output may not alias an input (taps of neighbouring strips)");
     BkParams p;
     memset(&p, 0, sizeof(p));
     p.ain = (const char*)d->a_in; p.xin = (const char*)d->x_in; p.xout = (char*)d->x_out; p.aout = (char*)d->a_out;
     p.w2b = (const char*)d->w2b; p.w2c = (const char*)d->w2c; p.w2a = (const char*)d->w2a;
+    p.pin = (const char*)d->p_in; p.wproj = (const char*)d->wproj; p.w2c_ld = w2c_ld;
     p.b2b = d->b2b; p.b2c = d->b2c; p.b2a = d->b2a;
     p.M = (int)M; p.H = d->H; p.W = d->W;
     p.nstrips = (int)((M + 31) / 32);
@@ -370,7 +405,14 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
         hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
     } while (0)
     const bool rowpp = rtn_bneck_rowpp(nt);
-    if (nt == 768) {
+    if (proj) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<false, 512, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((bottleneck64_kernel<false, 512, true, true>), dim3((unsigned)grid), dim3(512), BK_LDS, h->stream, p);
+    } else if (nt == 768) {
         if (rowpp) { if (tail) RTN_BK_LAUNCH(true, 768, true); else RTN_BK_LAUNCH(false, 768, true); }
         else       { if (tail) RTN_BK_LAUNCH(true, 768, false); else RTN_BK_LAUNCH(false, 768, false); }
     } else {

@@ -1426,12 +1426,12 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     // P4 0.062 -> 0.047.  RTN_CONV_H8=0 turns it off (A/B), RTN_CONV_IMPL=4 forces it like any other generation;
     // RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers), RTN_CONV_H8_STAGGER=0 runs
     // the two wave groups in lockstep (A/B: 0.181 ms on the head layer).
-    if (!s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16) {
+    if (!s2 && out8_scale == 0.f && (q8 ? d->dtype == RTN_FP8 && !query : d->dtype == RTN_BF16)) {
         const int h8 = rtn_env_int("RTN_CONV_H8", 1);
         const int forced = rtn_conv_impl_override();
         if (forced == 4 || (forced == 0 && h8 != 0)) {
             const int rc = rtn_conv_halo8_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0, forced == 4,
-                                              rtn_env_int("RTN_CONV_H8_MI", 0), ws_ptr, ws_cap, query, rtn_env_int("RTN_CONV_H8_KSPLIT", 0));
+                                              rtn_env_int("RTN_CONV_H8_MI", 0), ws_ptr, ws_cap, query, rtn_env_int("RTN_CONV_H8_KSPLIT", 0), q8);
             if (rc == RTN_OK && !query) h->last_conv_impl = 4;
             if (rc <= 0) return rc;                    // launched (or failed): done; 1 = not eligible, fall through
         }

@@ -61,9 +61,14 @@ struct H8Params {
     // small-M long-K layers (res5 branch2b: 34 row tiles x 2 column blocks, 72 K steps) are cut into S slices of gps (kh, chunk)
     // groups whose f32 partial sums go to slab[s][M][slab_ld] and are summed in slice order by ksplit_finish_kernel
     int ncb, S, gps, nitems, xcd;
+    int kh_fast;                  // group order: 1 = the kernel rows of a channel chunk back to back (the rows a tile re-reads for kh = 0, 1, 2 are
+                                  // then 1 group = 33 KB per CU apart instead of nchunk groups: they stay in the XCD's L2), 0 = chunks of a kernel row
     float* slab;
     unsigned slab_slice_bytes;
     int slab_ld;
+    // fp8 (OCP e4m3) operands (ES = 1): y = acc * acc_scale + bias; stored as bf16, or as e4m3 of clamp(y * out_scale, +-448)
+    float acc_scale, out_scale;
+    int out_fp8;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -105,6 +110,22 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// fp8 e4m3 x e4m3, K = 128 per instruction at twice the bf16 rate: a lane supplies 32 bytes of its row per operand - the two 16-byte
+// fragments the bf16 loop reads for k halves 0 and 1 (which 32 of the row's 128 K positions a lane holds is free as long as A and
+// B agree).  Block scales 2^0.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_fp8(f32x4& acc, const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    const i32x8 A = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8 B = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+
 // MI = row fragments (16 rows) per wave: tiles of R = 64 MI rows (256 or 192).  The host picks the height that needs the fewest
 // rounds of workgroups x rows (P3 at batch 8: 529 tiles of 256 rows = 3 rounds, 707 tiles of 192 rows = 3 shorter rounds).
 // EPI: bit 0 = residual add (keras Add / accumulated gradient contributions), bit 1 = ReLU mask of the tensor being differentiated
@@ -114,9 +135,12 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // NW: column fragments (16 channels) per wave.  8 = the 256-column tile above.  4 = a 128-column tile for the 65..128-channel layers
 // (res3 branch2b): wave tile 64 MI/4.. rows x 64 columns, a K step is TWO phases of {MI + 4 fragment reads | 4 MI MFMAs} (the same
 // reads-per-MFMA ratio as the wide tile), the B stage has two 64-row pieces, a lane ends up with 4 consecutive channels (8-byte stores).
-template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8>
+// ES: bytes per element.  2 = bf16.  1 = fp8 e4m3 (rtn_conv2d_fp8_fwd): the same LDS bytes (a 128-byte row is 128 K positions), a K step
+// is TWO phases of {fragment reads of both k halves | 4 MI MFMAs 16x16x128}, half the K steps per layer; bias / ReLU epilogue only.
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
     static_assert(NW == 8 || (NW == 4 && EPI == 0 && !SPLIT), "the half-width instance has the plain bias / ReLU epilogue only");
+    static_assert(ES == 2 || (ES == 1 && NW == 8 && EPI == 0 && !SPLIT), "the fp8 instance: full width, plain epilogue");
     constexpr int NBP = NW / 2;                        // 64-row pieces of a B stage
     constexpr int R = 64 * MI;                         // rows of a tile's halo image
     constexpr int TM = R - KW;                         // output rows per tile; halo rows 0 .. R - 2, row R - 1 = zeros
@@ -263,8 +287,8 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         sl = rem - cb * p.S;
         cboff = (unsigned)cb * 256u * (unsigned)p.Kbytes;
         const int g0 = sl * p.gps;
-        kh0 = g0 / nchunk;
-        cc0 = g0 - kh0 * nchunk;
+        if (p.kh_fast) { cc0 = g0 / p.KH; kh0 = g0 - cc0 * p.KH; }
+        else { kh0 = g0 / nchunk; cc0 = g0 - kh0 * nchunk; }
     };
     const int gps = SPLIT ? p.gps : G;                 // groups per item
 
@@ -340,6 +364,48 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }                                                                                            \
         H8_MFMA(1)                                                                                   \
     }
+    // The fp8 step: phase A = column fragments 0-3 (A fragments of BOTH k halves are read here and kept), phase B = fragments 4-7.
+    // DMA slots: the last piece of step s+1's B tile in phase A, the first three of step s+2's in phase B (their ring slot was last
+    // read in phase B of the step before, by the lagging wave group during this step's phase A).
+#define H8_MFMA8(HALF)                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
+            mma_fp8(acc[i_][(HALF) * 4 + j_], fa[i_], fa1[i_], fb[j_], fb1[j_]);                     \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_barrier();
+#define H8_STEP8F(KWI)                                                                               \
+    {                                                                                                \
+        const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
+        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
+        uint4 fa[MI], fa1[MI], fb[4], fb1[4];                                                        \
+        H8_LDA(KWI, 0)                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
+            fa1[i_] = *reinterpret_cast<const uint4*>(lds + (arow[KWI][i_] ^ 64u));                  \
+        H8_LDB(KWI, 0, 0)                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                             \
+            fb1[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ 64u) + (KWI) * B_STAGE + j_ * 2048); \
+        stage_b(3, kc_n1, ((KWI) + 1) % 3);                                                          \
+        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);             \
+        H8_MFMA8(0)                                                                                  \
+        H8_LDB(KWI, 0, 1)                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                             \
+            fb1[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ 64u) + (KWI) * B_STAGE + (4 + j_) * 2048); \
+        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
+        stage_b(1, kc_n2, ((KWI) + 2) % 3);                                                          \
+        stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
+        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);     \
+        {                                                                                            \
+            constexpr int na_ = (KWI) < 2 ? ((2 * (KWI) < MI) + (2 * (KWI) + 1 < MI)) : 0;           \
+            if (na_ == 2)      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                      \
+            else if (na_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+            else               asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
+        }                                                                                            \
+        H8_MFMA8(1)                                                                                  \
+    }
     // The half-width step: phase A = k half 0 + the LAST piece of step s+1's B tile, phase B = k half 1 + the FIRST piece of step
     // s+2's (its ring slot was last read two phases ago), halo pieces of the next group in both phases of taps 0 and 1.
 #define H8_STEP4(KWI)                                                                                \
@@ -371,15 +437,16 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NW; ++j) acc[i][j] = SPLIT ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
+            for (int j = 0; j < NW; ++j) acc[i][j] = (SPLIT || ES == 1) ? (f32x4){0.f, 0.f, 0.f, 0.f} : (f32x4){bias8[j], bias8[j], bias8[j], bias8[j]};
         int kh = kh0, cc = cc0;
         int rt1 = rt, cb1 = cb, sl1 = sl;
         unsigned cboff1 = cboff;
 #pragma unroll 1
         for (int g = 0; g < gps; ++g) {
             // the next group (kh1, cc1): of this item, or the first group of the workgroup's next item
-            int kh1 = kh, cc1 = cc + 1;
-            if (cc1 == nchunk) { cc1 = 0; ++kh1; }
+            int kh1 = kh, cc1 = cc;
+            if (p.kh_fast) { if (++kh1 == p.KH) { kh1 = 0; ++cc1; } }
+            else if (++cc1 == nchunk) { cc1 = 0; ++kh1; }
             if (g + 1 == gps) {
                 vidx += (int)gridDim.x;
                 item_decode(item_of(vidx), rt1, cb1, sl1, cboff1, kh1, cc1);
@@ -387,7 +454,11 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             }
             const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
             const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
-            if constexpr (NW == 8) {
+            if constexpr (ES == 1) {
+                H8_STEP8F(0)
+                H8_STEP8F(1)
+                H8_STEP8F(2)
+            } else if constexpr (NW == 8) {
                 H8_STEP(0)
                 H8_STEP(1)
                 H8_STEP(2)
@@ -407,7 +478,44 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         kh0 = kh; cc0 = cc;                            // the next item starts at the group the cursor already points to
         // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane (rows beyond TM / M go to an out-of-range
         // offset and are dropped)
-        if constexpr (NW == 4) {
+        if constexpr (ES == 1) {
+            const H8Group& Gc = p.g[gi];
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
+            const int ncol = wn * 128 + 8 * lrow;
+            const bool col_ok = ncol < p.N;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
+                    const int m = m0 + rloc;
+                    const bool ok = col_ok && rloc < TM && m < Gc.M;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = acc[i][j][r] * p.acc_scale + bias8[j];
+                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                    if (p.out_fp8) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float q = v[j] * p.out_scale;
+                            v[j] = q > 448.f ? 448.f : (q < -448.f ? -448.f : q);
+                        }
+                        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                        u32x2 o;
+                        o.x = pack_fp8x4(v[0], v[1], v[2], v[3]); o.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, (int)(ok ? (unsigned)m * (unsigned)p.out_ld + (unsigned)ncol : OOB), 0, 0);
+                        asm volatile("s_nop 3" :: "v"(o.x), "v"(o.y));
+                    } else {
+                        u32x4 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
+                        RTN_STORE_GUARD(o)
+                    }
+                }
+        } else if constexpr (NW == 4) {
             // 4 consecutive channels per lane and row: 8-byte stores
             const H8Group& Gc = p.g[gi];
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -526,6 +634,8 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         // item past the end are zeros from out-of-range offsets
     }
 #undef H8_STEP4
+#undef H8_STEP8F
+#undef H8_MFMA8
 #undef H8_STEP
 #undef H8_MFMA
 #undef H8_LDB
@@ -541,9 +651,11 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 // caller-owned workspace (K-slice slabs); `query` != nullptr: no launch, *query = workspace bytes this layer would use.
 // `ksplit_force`: 0 = cost model, 1 = never slice, n > 1 = n slices when n divides the group count.
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
-                       long long ws_cap, size_t* query, int ksplit_force) {
+                       long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8) {
     if (query) *query = 0;
-    if (d->dtype != RTN_BF16) return 1;
+    if (q8 ? d->dtype != RTN_FP8 : d->dtype != RTN_BF16) return 1;
+    const int es = q8 ? 1 : 2;                         // bytes per input / weight element
+    if (q8 && (query || (d->flags & ~RTN_CONV_RELU) || d->N <= 128 || d->N > 256)) return 1;     // fp8: one full-width column block, bias / ReLU
     if (d->KW != 3 || d->KH < 1 || d->KH > 7 || d->sy != 1 || d->sx != 1) return 1;
     if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
     if ((d->flags & RTN_CONV_MASK_PRE) && !(d->flags & RTN_CONV_RELU_MASK)) return 1;
@@ -553,12 +665,12 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (ncb > 1 && epi) return 1;
     const bool half = d->N <= 128;                     // the 128-column instance (NW = 4): plain epilogue, no slices
     if (half && (epi || (!forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0))) return 1;
-    if (d->Crun != d->pix_stride || (d->Crun * 2) % 128 || d->Crun <= 0) return 1;
+    if (d->Crun != d->pix_stride || (d->Crun * es) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
-    const int nchunk = d->Crun * 2 / 128;
+    const int nchunk = d->Crun * es / 128;
     const int G = d->KH * nchunk;
-    const long long Kbytes = (long long)d->KH * d->KW * d->Crun * 2;
+    const long long Kbytes = (long long)d->KH * d->KW * d->Crun * es;
     if (Kbytes * 256 * ncb >= 0xFFFFFF00ll) return 1;                  // the staging offsets of the last column block
     H8Params p;
     memset(&p, 0, sizeof(p));
@@ -568,13 +680,14 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     // Tile height (rows = 64 mi) and K slices by a cost model in microseconds: rounds of workgroups x K steps of an item (+ 5 for its
     // prologue / epilogue) x 1.53 us per 256-row step, + for S > 1 the finish launch and the slabs' round trip at 4 TB/s.
     // RTN_CONV_H8_MI / RTN_CONV_H8_KSPLIT pin them (A/B, tests).
-    const bool can_split = !half && d->ngroups == 1 && epi == 0 && ksplit_force != 1 && (ws_cap > 0 || query);
+    const bool can_split = !half && !q8 && d->ngroups == 1 && epi == 0 && ksplit_force != 1 && (ws_cap > 0 || query);
     const long long slab_ld = 256ll * ncb;
     int mi = 0, S = 1;
     {
         double best = 0;
         for (int cand = 4; cand >= 3; --cand) {
-            if (mi_force >= 3 && mi_force <= 4 && cand != mi_force) continue;
+            if (!q8 && mi_force >= 3 && mi_force <= 4 && cand != mi_force) continue;
+            if (q8 && cand == 4) continue;                 // fp8 holds both k halves' A fragments: the 256-row instance spills, 192 rows fit (256 VGPRs)
             long long t = 0;
             for (int i = 0; i < d->ngroups; ++i) t += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 64 * cand - 4) / (64 * cand - 3);
             const double step_us = 1.53 * (cand + 0.3) / 4.3;
@@ -621,11 +734,11 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         g.mask_bytes = (epi & 2) ? (unsigned)(s.mask_elems * 2) : 0u;
         g.in = (const char*)s.in;
         g.out = (char*)s.out;
-        g.in_bytes = (unsigned)(s.in_elems * 2);
-        g.out_bytes = (unsigned)(s.out_elems * 2);
+        g.in_bytes = (unsigned)(s.in_elems * es);
+        g.out_bytes = (unsigned)(s.out_elems * ((q8 && q8->out_dtype == RTN_FP8) ? 1 : 2));
         g.Hin = s.Hin; g.Win = s.Win; g.M = (int)M;
         g.tile_begin = (int)tiles;
-        g.in_row_stride_b = (int)(s.in_row_stride * 2);
+        g.in_row_stride_b = (int)(s.in_row_stride * es);
         g.inv_cells = 1.0f / (float)cells;
         g.inv_w = 1.0f / (float)s.Win;
         tiles += (M + TM - 1) / TM;
@@ -651,12 +764,14 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.relu = (d->flags & RTN_CONV_RELU) ? 1 : 0;
     p.out_ld = d->out_ld;
-    p.pix_b = d->pix_stride * 2;
+    p.pix_b = d->pix_stride * es;
+    if (q8) { p.acc_scale = q8->acc_scale; p.out_scale = q8->out_scale; p.out_fp8 = q8->out_dtype == RTN_FP8 ? 1 : 0; }
     p.res_ld = (epi & 1) ? d->g[0].res_ld : 0;
     p.mask_ld = (epi & 2) ? d->g[0].mask_ld : 0;
     p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
     p.ncb = ncb; p.S = S; p.gps = G / S; p.nitems = (int)items;
     p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;       // A/B knob: 0 = workgroup b starts at item b
+    p.kh_fast = rtn_env_int("RTN_CONV_H8_KHFAST", 1) != 0;
     p.slab = S > 1 ? ws : nullptr;
     p.slab_slice_bytes = S > 1 ? (unsigned)slice_bytes : 0u;
     p.slab_ld = (int)slab_ld;
@@ -683,9 +798,20 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 4>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
+#define RTN_H8_LAUNCH8F(M_)                                                                              \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, 0, false, 8, 1>,  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 8, 1>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
-        if (half) RTN_H8_LAUNCH4(M_);                                                                    \
+        if (q8) RTN_H8_LAUNCH8F(3);                                                                      \
+        else if (half) RTN_H8_LAUNCH4(M_);                                                               \
         else if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                \
         else if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0, false);      /* lockstep variant: A/B only */ \
         else if (epi == 0) RTN_H8_LAUNCH(M_, true, 0, false);                                            \
@@ -695,6 +821,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
+#undef RTN_H8_LAUNCH8F
 #undef RTN_H8_LAUNCH4
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");

@@ -47,7 +47,7 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 // integer environment knob, read on every call so that one process can A/B kernel variants (tools/ab_conv.py)
 int rtn_env_int(const char* name, int dflt);
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
-                       long long ws_cap, size_t* query, int ksplit_force);
+                       long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8 = nullptr);
 size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);
 int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n);
 int rtn_wgrad_halo_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);

@@ -296,6 +296,21 @@ class Engine:
         s2.Hin, s2.Win, s2.C, s2.step = x.shape[1], x.shape[2], x.shape[3], fb["step"]
         return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
+    def _bneck_proj_op(self, fb, B):
+        """The FIRST block of the 64-channel stage as one launch: branch2b, then branch2c and the projection shortcut as one product
+        over the K-concatenated filters of _dual_weights() (rtn_bottleneck64_fwd with p_in / wproj)."""
+        wd, bd = self._dual_weights()[fb["key"]]
+        w2b, b2b = self.w[fb["n2b"]][:2]
+        a, x, y = fb["a"], fb["x"], fb["y"]
+        d = L.BottleneckDesc()
+        d.a_in, d.a_in_elems = a.data_ptr(), a.numel()
+        d.p_in, d.p_in_elems = x.data_ptr(), x.numel()
+        d.x_out, d.x_out_elems = y.data_ptr(), y.numel()
+        d.w2b, d.b2b, d.w2c, d.b2c = w2b.data_ptr(), b2b.data_ptr(), wd.data_ptr(), bd.data_ptr()
+        d.wproj, d.w2c_ld = wd.data_ptr() + 64 * wd.element_size(), wd.shape[1]
+        d.batch, d.H, d.W, d.mid, d.dtype = B, fb["Ho"], fb["Wo"], 64, self.rdt
+        return ("bneck", d, fb["n2b"] + "+2c+1", {"xs": [a, x], "ys": [y], "B": B, "H": fb["Ho"], "W": fb["Wo"], "tail": False, "proj": True})
+
     def _bneck_op(self, blk, nxt, B):
         """An identity block of the 64-channel stage as one launch (rtn_bottleneck64_fwd): branch2b + branch2c + Add + ReLU of
         `blk`, and branch2a of the following identity block `nxt` when there is one."""
@@ -395,6 +410,7 @@ class Engine:
                     i_2a = len(ops) - 1
                     b2 = buf(B, Ho, Wo, f)
                     ops.append(self._conv(n2b, [self._group(a, b2, Ho, Wo)], B, pad=(1, 1), flags=L.CONV_RELU))
+                    i_2b_cur = len(ops) - 1
                     if f >= 128:
                         a_acts[n2a] = a
                     if f == 64 and block > 0:
@@ -411,7 +427,8 @@ class Engine:
                                       flags=L.CONV_RELU | L.CONV_RES_SAME))
                 if block == 0:
                     first_blocks.append({"key": "res%s%s" % (s, bname), "i_b1": i_b1, "i_2c": len(ops) - 1, "x": x, "b2": b2, "y": y,
-                                         "Ho": Ho, "Wo": Wo, "step": st, "f": f})
+                                         "Ho": Ho, "Wo": Wo, "step": st, "f": f, "a": a, "n2b": n2b,
+                                         "i_2b": None if (fp8_on and ("a", n2a) in self.fp8_scales) else i_2b_cur})
                 if blocks64 and blocks64[-1].get("y") is None and blocks64[-1]["n2c"] == "res%s%s_branch2c" % (s, bname):
                     blocks64[-1].update({"i_2c": len(ops) - 1, "y": y})
                 x = y
@@ -503,6 +520,11 @@ class Engine:
                         for fb in first_blocks:
                             v[fb["i_2c"]] = self._dual_op(fb, B)
                             v[fb["i_b1"]] = None
+                    if fk and fd:                            # res2a: branch2b + [branch2c | branch1] + ReLU as one launch
+                        for fb in first_blocks:
+                            if fb["f"] == 64 and fb["step"] == 1 and fb["i_2b"] is not None:
+                                v[fb["i_2b"]] = self._bneck_proj_op(fb, B)
+                                v[fb["i_2c"]] = None
                     if fk:
                         for bi, blk in enumerate(blocks64):
                             nxt = blocks64[bi + 1] if bi + 1 < len(blocks64) else None      # its branch2a rides along

@@ -75,9 +75,49 @@ def test_bottleneck64_kernel(pkg, handle, B, H, W, tail):
     assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -4
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 9, 13), (1, 40, 67), (8, 25, 42), (1, 1, 1)])
+def test_bottleneck64_projection_shortcut_form(pkg, handle, B, H, W):
+    """The stage's first block (res2a): x_out = relu(conv1x1(h1; w2c) + conv1x1(p; wproj) + (b2c + b1)) with the K-concatenated
+    [branch2c | branch1] filters of rtn_conv1x1_dual_fwd (w2c_ld = 128, wproj = w2c + 64 elements)."""
+    L = pkg._lib
+    g = torch.Generator().manual_seed(H * 10 + W)
+    dev = torch.device("cuda")
+    a = torch.relu(torch.randn(B, H, W, 64, generator=g, dtype=torch.float64))
+    pin = torch.relu(torch.randn(B, H, W, 64, generator=g, dtype=torch.float64))
+    w2b = torch.randn(64, 3, 3, 64, generator=g, dtype=torch.float64) / 24.0
+    wcat = torch.randn(256, 128, generator=g, dtype=torch.float64) / 8.0            # [branch2c | branch1] along K
+    b2b, bsum = torch.randn(64, generator=g, dtype=torch.float64) * 0.3, torch.randn(256, generator=g, dtype=torch.float64) * 0.3
+    aq, pq, wbq, wq = bf(a), bf(pin), bf(w2b), bf(wcat)
+    h1 = F.conv2d(aq.permute(0, 3, 1, 2), wbq.permute(0, 3, 1, 2), b2b.float().double(), padding=1).permute(0, 2, 3, 1)
+    h1 = bf(torch.relu(h1))
+    xo = bf(torch.relu(h1 @ wq[:, :64].T + pq @ wq[:, 64:].T + bsum.float().double()))
+    t16 = lambda t: t.to(torch.bfloat16).to(dev).contiguous()
+    ad, pd, wbd, wd = t16(a), t16(pin), t16(w2b.reshape(64, 576)), t16(wcat)
+    bbd, bcd = b2b.float().to(dev), bsum.float().to(dev)
+    xout = torch.full((B, H, W, 256), -7.0, dtype=torch.bfloat16, device=dev)
+    d = L.BottleneckDesc()
+    d.a_in, d.a_in_elems, d.p_in, d.p_in_elems = ad.data_ptr(), ad.numel(), pd.data_ptr(), pd.numel()
+    d.x_out, d.x_out_elems = xout.data_ptr(), xout.numel()
+    d.w2b, d.b2b, d.w2c, d.b2c = wbd.data_ptr(), bbd.data_ptr(), wd.data_ptr(), bcd.data_ptr()
+    d.wproj, d.w2c_ld = wd.data_ptr() + 128, 128
+    d.batch, d.H, d.W, d.mid, d.dtype = B, H, W, 64, L.RTN_BF16
+    handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    first = xout.clone()
+    ex, sx = float((xout.cpu().double() - xo).abs().max()), max(1.0, float(xo.abs().max()))
+    print("x_out: max err %.3e of scale %.2f" % (ex, sx))
+    assert ex <= 1e-2 * sx
+    handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    assert torch.equal(first, xout)
+    aout = torch.zeros(B, H, W, 64, dtype=torch.bfloat16, device=dev)
+    d.a_out, d.a_out_elems = aout.data_ptr(), aout.numel()
+    assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1          # no next-branch2a output in this form
+
+
 def test_engine_with_fused_bottlenecks_matches_separate_layers(pkg):
-    """Engine level: res2b / res2c as fused launches (inference, bf16) against the same engine running the three convolutions of
-    each block separately.  Both round the same tensors to bf16 at the same points; the f32 summation order differs, so the C2..C5
+    """Engine level: res2a (projection-shortcut form), res2b and res2c as fused launches (inference, bf16) against the same engine
+    running the convolutions of each block separately.  Both round the same tensors to bf16 at the same points; the f32 summation order differs, so the C2..C5
     feature maps agree to 2^-6 of their scale (stated; the measured value is printed) and the op list really contains the fused ops."""
     E = importlib.import_module(pkg.__name__ + ".engine")
     Wt = importlib.import_module(pkg.__name__ + ".weights")
@@ -95,7 +135,7 @@ def test_engine_with_fused_bottlenecks_matches_separate_layers(pkg):
         eng.forward(x)
         torch.cuda.synchronize()
         kinds = [op[0] for op in eng.active_ops(plan)]
-        assert (kinds.count("bneck") == 2) == fuse
+        assert kinds.count("bneck") == (3 if fuse else 0)
         feats[fuse] = [t.float().cpu().clone() for t in plan["feats"]]
     for lvl, (a, b) in enumerate(zip(feats[False], feats[True])):
         scale = float(a.abs().max())

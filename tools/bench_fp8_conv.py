@@ -68,7 +68,8 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         res[name] = ms
-        print("%-5s %.3f ms per layer launch, %.0f TFLOP/s (%.1f GFLOP)" % (name, ms, flop / ms / 1e9, flop / 1e9))
+        print("%-5s %.3f ms per layer launch, %.0f TFLOP/s (%.1f GFLOP), kernel generation %d" %
+              (name, ms, flop / ms / 1e9, flop / 1e9, pkg.lib.rtn_debug_last_conv_impl(h.raw)))
     print("fp8 / bf16 time: %.2f" % (res["fp8"] / res["bf16"]))
 
 
