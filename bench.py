@@ -84,21 +84,26 @@ def pmc_traffic(n_conv_launches):
     NOT collected in this run: the file is only quoted when it was collected on the same launch plan (conv launches per step),
     and the line says which file and commit.  Returns (bytes_per_step or None, note)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))          # rN_vM_...: the name orders them
     if not files:
         return None, "no PMC summary committed"
-    path = files[-1]
-    try:
-        with open(path) as f:
-            j = json.load(f)
-        tot = j["conv_total"]
-        launches = j.get("bench_launches_per_step")
-    except (OSError, KeyError, ValueError) as e:
-        return None, "unreadable PMC summary %s: %s" % (os.path.basename(path), e)
-    tag = "profiles/%s (commit %s, plan of %s conv launches/step, 2 x FETCH_SIZE + WRITE_SIZE)" % (
-        os.path.basename(path), j.get("git_commit", "unrecorded"), launches)
-    if launches is None or int(launches) != int(n_conv_launches):
-        return None, "stale: %s, this plan has %d" % (tag, n_conv_launches)
+    note = None
+    for path in reversed(files):                     # the latest summary collected on THIS launch plan
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            tot = j["conv_total"]
+            launches = j.get("bench_launches_per_step")
+        except (OSError, KeyError, ValueError) as e:
+            note = note or "unreadable PMC summary %s: %s" % (os.path.basename(path), e)
+            continue
+        tag = "profiles/%s (commit %s, plan of %s conv launches/step, 2 x FETCH_SIZE + WRITE_SIZE)" % (
+            os.path.basename(path), j.get("git_commit", "unrecorded"), launches)
+        if launches is not None and int(launches) == int(n_conv_launches):
+            break
+        note = note or "stale: %s, this plan has %d" % (tag, n_conv_launches)
+    else:
+        return None, note
     return float(tot["hbm_bytes_per_step"]), tag
 
 
