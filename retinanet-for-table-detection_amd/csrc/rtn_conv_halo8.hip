@@ -25,6 +25,10 @@
 // LDS (160 KiB, all of it): B ring 3 x 32 KiB at 0, halos 2 x 32 KiB at 96 KiB.  One workgroup (512 threads) per CU.
 #include "rtn_internal.h"
 
+#ifndef RTN_H8_ABLATE
+#define RTN_H8_ABLATE 0
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -137,8 +141,11 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // reads-per-MFMA ratio as the wide tile), the B stage has two 64-row pieces, a lane ends up with 4 consecutive channels (8-byte stores).
 // ES: bytes per element.  2 = bf16.  1 = fp8 e4m3 (rtn_conv2d_fp8_fwd): the same LDS bytes (a 128-byte row is 128 K positions), a K step
 // is TWO phases of {fragment reads of both k halves | 4 MI MFMAs 16x16x128}, half the K steps per layer; bias / ReLU epilogue only.
-template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2>
+// PH2 (bf16): the fp8 instance's two fat phases per K step (both k halves of four column fragments per phase: 8 MI MFMAs between
+// barriers instead of 4 MI), for the 192-row tile whose registers have room for the second set of fragments.
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2, bool PH2 = false>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
+    static_assert(!PH2 || (ES == 2 && NW == 8 && MI <= 3), "two-phase bf16 steps: full width, 192-row tiles");
     static_assert(NW == 8 || (NW == 4 && EPI == 0 && !SPLIT), "the half-width instance has the plain bias / ReLU epilogue only");
     static_assert(ES == 2 || (ES == 1 && NW == 8 && EPI == 0 && !SPLIT), "the fp8 instance: full width, plain epilogue");
     constexpr int NBP = NW / 2;                        // 64-row pieces of a B stage
@@ -217,11 +224,15 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         const int dy = kh - p.pad_t;
         const unsigned delta = (unsigned)(dy * st_row_b + cc * 128);
         const bool ok = (unsigned)(hiy[i] + dy) < (unsigned)st_Hin;
+#if !(RTN_H8_ABLATE & 2)          // timing ablations (wrong results): -DRTN_H8_ABLATE=1 no weight staging, 2 no halo staging, 4 no MFMAs
         dma16(in_srd, ok ? hbase[i] + delta : OOB, 0u, lds_base + abuf_addr + (unsigned)(wave * 1024 + i * 8192));
+#endif
     };
     // one B piece (d) of the K column block `kcol` (bytes) into ring stage `bst`
     auto stage_b = [&](int d, unsigned kcol, int bst) {
+#if !(RTN_H8_ABLATE & 1)
         dma16(w_srd, wrow_off[d], kcol, lds_base + (unsigned)bst * B_STAGE + (unsigned)(wave * 1024 + d * 8192));
+#endif
     };
 
     // compute tile: A fragment read offsets per tap (k half 0; half 1 = ^ 64), the zero row where the tap leaves the image.
@@ -319,14 +330,20 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #define H8_LDB(KWI, KS, HALF)                                                                        \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
         fb[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ ((KS) * 64u)) + (KWI) * B_STAGE + ((HALF) * 4 + j_) * 2048);
+#if RTN_H8_ABLATE & 4
+#define H8_MMA(I_, J_, HALF) asm volatile("" :: "v"(fa[I_].x), "v"(fa[I_].w), "v"(fb[J_].x), "v"(fb[J_].w));
+#else
+#define H8_MMA(I_, J_, HALF)                                                                         \
+    acc[I_][(HALF) * 4 + J_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                              \
+        __builtin_bit_cast(bf16x8, fa[I_]), __builtin_bit_cast(bf16x8, fb[J_]), acc[I_][(HALF) * 4 + J_], 0, 0, 0);
+#endif
 #define H8_MFMA(HALF)                                                                                \
     __builtin_amdgcn_s_barrier();                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
-            acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-                __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
+            H8_MMA(i_, j_, HALF)                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_barrier();
@@ -373,7 +390,13 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
-            mma_fp8(acc[i_][(HALF) * 4 + j_], fa[i_], fa1[i_], fb[j_], fb1[j_]);                     \
+            if constexpr (ES == 1) mma_fp8(acc[i_][(HALF) * 4 + j_], fa[i_], fa1[i_], fb[j_], fb1[j_]); \
+            else {                                                                                   \
+                acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                    __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
+                acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
+                    __builtin_bit_cast(bf16x8, fa1[i_]), __builtin_bit_cast(bf16x8, fb1[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
+            }                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_barrier();
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             }
             const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
             const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
-            if constexpr (ES == 1) {
+            if constexpr (ES == 1 || PH2) {
                 H8_STEP8F(0)
                 H8_STEP8F(1)
                 H8_STEP8F(2)
@@ -638,6 +661,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #undef H8_MFMA8
 #undef H8_STEP
 #undef H8_MFMA
+#undef H8_MMA
 #undef H8_LDB
 #undef H8_LDA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
@@ -705,6 +729,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     }
     if (S > 1 && !query && (!ws || ((uintptr_t)ws & 15))) return 1;
     const bool split = ncb > 1 || S > 1;
+    const bool ph2 = !q8 && !half && !split && epi == 0 && mi == 3 && stagger && rtn_env_int("RTN_CONV_H8_PH2", 0) != 0;
     const int TM = 64 * mi - 3;
     long long tiles = 0;
     for (int i = 0; i < d->ngroups; ++i) {
@@ -808,9 +833,20 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 8, 1>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
+#define RTN_H8_LAUNCH_PH2()                                                                              \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, 3, true, 0, false, 8, 2, true>, \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, 3, true, 0, false, 8, 2, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
         if (q8) RTN_H8_LAUNCH8F(3);                                                                      \
+        else if (ph2) RTN_H8_LAUNCH_PH2();                                                               \
         else if (half) RTN_H8_LAUNCH4(M_);                                                               \
         else if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                \
         else if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0, false);      /* lockstep variant: A/B only */ \
@@ -821,6 +857,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
+#undef RTN_H8_LAUNCH_PH2
 #undef RTN_H8_LAUNCH8F
 #undef RTN_H8_LAUNCH4
 #undef RTN_H8_LAUNCH
