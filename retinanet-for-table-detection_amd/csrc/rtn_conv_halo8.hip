@@ -31,6 +31,21 @@
 
 namespace {
 
+// -DRTN_H8_STAMP: in-kernel time stamps (s_memtime) of one K step of workgroup 0, waves 0 and 4, read back by rtn_debug_h8_stamps
+// (tools/h8_stamps.py).  Not in production builds.
+#ifdef RTN_H8_STAMP
+__device__ unsigned long long g_h8_stamps[2][64];
+#define H8_STAMP(K_)                                                                                 \
+    if (stamp_on) {                                                                                  \
+        unsigned long long t_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                 \
+        if (lane == 0 && stamp_n < 64) g_h8_stamps[grp][stamp_n] = t_;                               \
+        ++stamp_n;                                                                                   \
+    }
+#else
+#define H8_STAMP(K_)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -143,8 +158,13 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // is TWO phases of {fragment reads of both k halves | 4 MI MFMAs 16x16x128}, half the K steps per layer; bias / ReLU epilogue only.
 // PH2 (bf16): the fp8 instance's two fat phases per K step (both k halves of four column fragments per phase: 8 MI MFMAs between
 // barriers instead of 4 MI), for the 192-row tile whose registers have room for the second set of fragments.
-template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2, bool PH2 = false>
+// NB: ONE barrier per K step instead of eight (experiment): the phase barriers only enforce the alternation of the two wave groups,
+// correctness needs a barrier between "step s+1's tile has landed for every wave" and its first read, and between the last read of a
+// ring slot and its restaging - both are met by one barrier at the top of a step.  All eight waves then run the same program and
+// the hardware interleaves the two waves of a SIMD as it sees fit.
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2, bool PH2 = false, bool NB = false>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
+    static_assert(!NB || (!STAGGER && ES == 2 && NW == 8 && !PH2), "the one-barrier step: full width bf16, no stagger");
     static_assert(!PH2 || (ES == 2 && NW == 8 && MI <= 3), "two-phase bf16 steps: full width, 192-row tiles");
     static_assert(NW == 8 || (NW == 4 && EPI == 0 && !SPLIT), "the half-width instance has the plain bias / ReLU epilogue only");
     static_assert(ES == 2 || (ES == 1 && NW == 8 && EPI == 0 && !SPLIT), "the fp8 instance: full width, plain epilogue");
@@ -157,6 +177,10 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int grp = wave >> 2;                         // SIMD partners (w, w + 4) sit in different groups
+#ifdef RTN_H8_STAMP
+    bool stamp_on = false, first_item = true;
+    int stamp_n = 0;
+#endif
     const int wm = wave >> 1, wn = wave & 1;           // wave tile: rows [16 MI wm, + 16 MI) x columns [128 wn, +128)
     const int lr = lane >> 3, sc = (lane & 7) ^ lr;    // staging: row inside an 8-row piece, SOURCE chunk (swizzle on the source)
     const int lrow = lane & 15, kq = lane >> 4;        // fragment row / k quarter of this lane
@@ -338,7 +362,9 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         __builtin_bit_cast(bf16x8, fa[I_]), __builtin_bit_cast(bf16x8, fb[J_]), acc[I_][(HALF) * 4 + J_], 0, 0, 0);
 #endif
 #define H8_MFMA(HALF)                                                                                \
+    H8_STAMP(1)                                                                                      \
     __builtin_amdgcn_s_barrier();                                                                    \
+    H8_STAMP(2)                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
@@ -346,7 +372,9 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             H8_MMA(i_, j_, HALF)                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    __builtin_amdgcn_s_barrier();
+    H8_STAMP(3)                                                                                      \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    H8_STAMP(4)
     // One K step = tap KWI of the current group.  DMA slots (see the header): phase 1 the LAST piece of step s+1's B tile,
     // phases 2-4 the first three pieces of step s+2's, halo pieces of the next group in phases 2 and 4 of taps 0 and 1.
     // kc_n1 / kc_n2: K column blocks of steps s+1 / s+2.
@@ -380,6 +408,38 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             else               asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
         }                                                                                            \
         H8_MFMA(1)                                                                                   \
+    }
+#define H8_STEP_NB(KWI)                                                                              \
+    {                                                                                                \
+        const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
+        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
+        __builtin_amdgcn_s_barrier();                                                                \
+        stage_b(3, kc_n1, ((KWI) + 1) % 3);                                                          \
+        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
+        stage_b(1, kc_n2, ((KWI) + 2) % 3);                                                          \
+        stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
+        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);             \
+        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);     \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                        \
+            uint4 fa[MI];                                                                            \
+            _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                        \
+                fa[i_] = *reinterpret_cast<const uint4*>(lds + (arow[KWI][i_] ^ (ks_ * 64u)));       \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                       \
+                uint4 fb[4];                                                                         \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
+                    fb[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ (ks_ * 64u)) + (KWI) * B_STAGE + (h_ * 4 + j_) * 2048); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
+                    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                \
+                        acc[i_][h_ * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+                            __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][h_ * 4 + j_], 0, 0, 0); \
+            }                                                                                        \
+        }                                                                                            \
+        {                                                                                            \
+            constexpr int na_ = (KWI) < 2 ? ((2 * (KWI) < MI) + (2 * (KWI) + 1 < MI)) : 0;           \
+            if (na_ == 2)      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                      \
+            else if (na_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
+            else               asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
+        }                                                                                            \
     }
     // The fp8 step: phase A = column fragments 0-3 (A fragments of BOTH k halves are read here and kept), phase B = fragments 4-7.
     // DMA slots: the last piece of step s+1's B tile in phase A, the first three of step s+2's in phase B (their ring slot was last
@@ -475,9 +535,16 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                 item_decode(item_of(vidx), rt1, cb1, sl1, cboff1, kh1, cc1);
                 stage_tile(rt1);
             }
+#ifdef RTN_H8_STAMP
+            stamp_on = blockIdx.x == 0 && (wave & 3) == 0 && first_item && g == 4;
+#endif
             const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
             const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
-            if constexpr (ES == 1 || PH2) {
+            if constexpr (NB) {
+                H8_STEP_NB(0)
+                H8_STEP_NB(1)
+                H8_STEP_NB(2)
+            } else if constexpr (ES == 1 || PH2) {
                 H8_STEP8F(0)
                 H8_STEP8F(1)
                 H8_STEP8F(2)
@@ -653,11 +720,15 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
             }
         }
         rt = rt1; cb = cb1; sl = sl1; cboff = cboff1;
+#ifdef RTN_H8_STAMP
+        first_item = false;
+#endif
         // the staging cursor's halo rows already belong to the next item (switched in the last group); the pieces it issued for an
         // item past the end are zeros from out-of-range offsets
     }
 #undef H8_STEP4
 #undef H8_STEP8F
+#undef H8_STEP_NB
 #undef H8_MFMA8
 #undef H8_STEP
 #undef H8_MFMA
@@ -729,6 +800,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     }
     if (S > 1 && !query && (!ws || ((uintptr_t)ws & 15))) return 1;
     const bool split = ncb > 1 || S > 1;
+    const bool nb = !q8 && !half && !split && epi == 0 && rtn_env_int("RTN_CONV_H8_NB", 0) != 0;
     const bool ph2 = !q8 && !half && !split && epi == 0 && mi == 3 && stagger && rtn_env_int("RTN_CONV_H8_PH2", 0) != 0;
     const int TM = 64 * mi - 3;
     long long tiles = 0;
@@ -843,9 +915,20 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, 3, true, 0, false, 8, 2, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
+#define RTN_H8_LAUNCH_NB(M_)                                                                             \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, false, 0, false, 8, 2, false, true>, \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, false, 0, false, 8, 2, false, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
         if (q8) RTN_H8_LAUNCH8F(3);                                                                      \
+        else if (nb) RTN_H8_LAUNCH_NB(M_);                                                               \
         else if (ph2) RTN_H8_LAUNCH_PH2();                                                               \
         else if (half) RTN_H8_LAUNCH4(M_);                                                               \
         else if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                \
@@ -857,6 +940,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
+#undef RTN_H8_LAUNCH_NB
 #undef RTN_H8_LAUNCH_PH2
 #undef RTN_H8_LAUNCH8F
 #undef RTN_H8_LAUNCH4
@@ -865,3 +949,9 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (S > 1) return rtn_conv_ksplit_finish(h, ws, S, Mtot, d->N, (int)slab_ld, d->bias, p.relu, d->g[0].out, d->out_ld);
     return RTN_OK;
 }
+
+#ifdef RTN_H8_STAMP
+extern "C" int rtn_debug_h8_stamps(unsigned long long* out128) {
+    return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_h8_stamps), sizeof(unsigned long long) * 128, 0, hipMemcpyDeviceToHost);
+}
+#endif
