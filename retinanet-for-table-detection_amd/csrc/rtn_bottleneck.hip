@@ -48,7 +48,6 @@ struct BkParams {
     const float* b2a;
     int M, H, W, nstrips;
     float inv_cells, inv_w;
-    int phase_sleep;        // start delay per wave index, in units of 64 cycles (see the de-phasing note in the kernel)
     int dbg;                // timing ablation only (RTN_BNECK_DBG): 1 drop the 3x3's loads, 2 the shortcut loads, 4 the x_out stores, 8 the a_out stores
 };
 
@@ -388,7 +387,6 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
     p.inv_w = 1.0f / (float)d->W;
     { const char* e = getenv("RTN_BNECK_DBG"); p.dbg = (e && *e) ? atoi(e) : 0; }
-    { const char* e = getenv("RTN_BNECK_PHASE"); p.phase_sleep = (e && *e) ? atoi(e) : 64; }
     // 12 waves per CU (154 VGPRs: three per SIMD) keep 1.5 x the loads of 8 in flight; RTN_BNECK_THREADS=512 for the A/B
     const int nt = rtn_bneck_threads();
     int grid = h->num_cus > 0 ? h->num_cus : 256;

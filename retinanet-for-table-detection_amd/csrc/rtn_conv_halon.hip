@@ -57,7 +57,7 @@ struct HNParams {
     const float* bias;
     unsigned w_bytes;
     int ngroups, ntiles;
-    int N, Kbytes, nchunk, pad_t, pad_l, relu, sigmoid, out_ld, pix_b, vec, xcd;
+    int N, Kbytes, nchunk, pad_t, pad_l, relu, sigmoid, out_ld, pix_b, vec, xcd, kh_fast;
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -175,7 +175,14 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
             dma16(w_srd, wvoff[d], kcol, lds_base + (P < Cfg::BP ? st_ring + HN_HALO + (unsigned)P * 1024u : Cfg::DUMP));
         }
         st_ring = st_ring == 2 * Cfg::STAGE ? 0u : st_ring + Cfg::STAGE;
-        if (++st_cc == nchunk) {
+        // kernel rows of a channel chunk back to back: the image rows a tile re-reads for kh = 0, 1, 2 are then one stage apart and
+        // still in the XCD's L2 (RTN_CONV_H8_KHFAST=0: chunks of a kernel row back to back, A/B)
+        if (p.kh_fast) {
+            if (++st_kh == 3) {
+                st_kh = 0;
+                if (++st_cc == nchunk) { st_cc = 0; st_v += (int)gridDim.x; stage_tile(tile_of(st_v)); }
+            }
+        } else if (++st_cc == nchunk) {
             st_cc = 0;
             if (++st_kh == 3) {
                 st_kh = 0;
@@ -371,6 +378,7 @@ int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.pix_b = d->pix_stride * 2;
     p.vec = vec ? 1 : 0;
     p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;
+    p.kh_fast = rtn_env_int("RTN_CONV_H8_KHFAST", 1) != 0;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;

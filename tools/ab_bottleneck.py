@@ -13,7 +13,7 @@ fused = [op for op in eng.active_ops(plan) if op[0] == "bneck"]
 plain = {op[2]: op for op in plan["ops"] if op[0] == "conv"}
 variants = [{"RTN_BNECK_THREADS": t, "RTN_BNECK_ROWPP": "0", "RTN_BNECK_DBG": "0"} for t in ("512", "768")]
 if "--phase" in sys.argv:         # start delay per wave index (x 64 cycles)
-    variants = [{"RTN_BNECK_THREADS": t, "RTN_BNECK_ROWPP": "0", "RTN_BNECK_DBG": "0", "RTN_BNECK_PHASE": ph} for t in ("512", "768") for ph in ("0", "16", "32", "64", "96", "128")]
+    raise SystemExit("--phase: the per-wave start delay experiment (no effect, profiles/r2_v2_bottleneck_fused.txt) was removed from the kernel")
 if "--ablate" in sys.argv:        # which stream bounds the kernel: drop one at a time (timing only, outputs are wrong)
     variants = [{"RTN_BNECK_THREADS": "512", "RTN_BNECK_ROWPP": "0", "RTN_BNECK_DBG": d} for d in ("0", "1", "2", "4", "8", "3", "12", "15")]
 
@@ -43,6 +43,6 @@ for op in fused:
         if rnd >= 2: times[len(variants)].append(t)
     for i, v in enumerate(variants):
         med = statistics.median(times[i])
-        print("%-28s threads %s rowpp %s: median %.4f ms  min %.4f  (%.2f TB/s)" % (op[2], v["RTN_BNECK_THREADS"], v["RTN_BNECK_ROWPP"] + " dbg " + v["RTN_BNECK_DBG"] + " phase " + v.get("RTN_BNECK_PHASE", "-"), med, min(times[i]), by / med / 1e9))
+        print("%-28s threads %s rowpp %s: median %.4f ms  min %.4f  (%.2f TB/s)" % (op[2], v["RTN_BNECK_THREADS"], v["RTN_BNECK_ROWPP"] + " dbg " + v["RTN_BNECK_DBG"], med, min(times[i]), by / med / 1e9))
     med = statistics.median(times[len(variants)])
     print("%-28s separate launches %s: median %.4f ms" % (op[2], "+".join(n.split("_")[1] for n in names), med))
