@@ -212,6 +212,8 @@ typedef struct {
      * filters of rtn_conv1x1_dual_fwd ([4*mid][mid + mid]): w2c = that matrix, wproj = w2c + mid elements, w2c_ld = 2 * mid. */
     const void* p_in;  int64_t p_in_elems;
     const void* wproj;
+    /* optional: branch2b's output h1 [batch][H][W][mid] is also written (the training forward keeps it for the backward pass) */
+    void*       h1_out; int64_t h1_out_elems;
 } rtn_bottleneck_desc_t;
 int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d);
 

@@ -80,6 +80,7 @@ class BottleneckDesc(C.Structure):
         ("w2b", C.c_void_p), ("b2b", C.c_void_p), ("w2c", C.c_void_p), ("b2c", C.c_void_p), ("w2a", C.c_void_p), ("b2a", C.c_void_p),
         ("batch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("mid", C.c_int32), ("dtype", C.c_int32), ("w2c_ld", C.c_int32),
         ("p_in", C.c_void_p), ("p_in_elems", C.c_int64), ("wproj", C.c_void_p),
+        ("h1_out", C.c_void_p), ("h1_out_elems", C.c_int64),
     ]
 
 

@@ -37,6 +37,7 @@ struct BkParams {
     const char* xin;        // [M][256] bf16: the block input (identity shortcut)
     char* xout;             // [M][256] bf16
     char* aout;             // [M][64]  bf16 or nullptr: the next block's branch2a output
+    char* h1out;            // [M][64]  bf16 or nullptr: branch2b's output (training keeps it for the backward pass)
     const char* w2b;        // [64][3*3*64] bf16, BN folded
     const char* w2c;        // [256][64]
     const char* w2a;        // [64][256] (next block), or nullptr
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.ain, 0, p.M * 128, 0x00020000);
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(PROJ ? p.pin : p.xin), 0, PROJ ? p.M * 128 : p.M * 512, 0x00020000);
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.xout, 0, p.M * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.h1out ? p.h1out : p.xout), 0, p.h1out ? p.M * 128 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t n_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? p.aout : p.xout), 0, TAIL ? p.M * 128 : 0, 0x00020000);
 
     // A-operand (weight) fragment of image `im`, row fragment f, k half ks: lane (kq = q, row c) reads row 16 f + c
@@ -241,6 +243,15 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 h1[s][u] = make_uint4(pack2(relu(lo[0]), relu(lo[1])), pack2(relu(lo[2]), relu(lo[3])),
                                       pack2(relu(hi[0]), relu(hi[1])), pack2(relu(hi[2]), relu(hi[3])));
             }
+        if (p.h1out) {              // uniform: the training forward keeps branch2b's activation (lane: 8 consecutive channels of a pixel)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const u32x4 ov = {h1[s][u].x, h1[s][u].y, h1[s][u].z, h1[s][u].w};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, h_rsrc, (int)gc.aoff[u], s * 64, 0);
+                }
+        }
         // ---- G2 (branch2c + shortcut + ReLU) in four 64-channel chunks, each feeding G3 (next branch2a) as one k chunk
         f32x4 acc3[4][2];
 #pragma unroll
@@ -375,10 +386,13 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
         return rtn_fail(h, RTN_EINVAL, "bottleneck64: a_out needs aligned w2a / b2a");
     if (d->a_in_elems < M * 64 || (!proj && d->x_in_elems < M * 256) || d->x_out_elems < M * 256 || (tail && d->a_out_elems < M * 64))
         return rtn_fail(h, RTN_EBOUNDS, "bottleneck64: a tensor is smaller than batch x H x W x channels");
+    if (d->h1_out && (((uintptr_t)d->h1_out & 15) || d->h1_out_elems < M * 64 || d->h1_out == d->a_in))
+        return rtn_fail(h, RTN_EINVAL, "bottleneck64: h1_out must be an aligned [M][64] tensor other than a_in");
     if ((!proj && d->x_out == d->x_in) || d->x_out == d->a_in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the output may not alias an input (taps of neighbouring strips)");
     BkParams p;
     memset(&p, 0, sizeof(p));
     p.ain = (const char*)d->a_in; p.xin = (const char*)d->x_in; p.xout = (char*)d->x_out; p.aout = (char*)d->a_out;
+    p.h1out = (char*)d->h1_out;
     p.w2b = (const char*)d->w2b; p.w2c = (const char*)d->w2c; p.w2a = (const char*)d->w2a;
     p.pin = (const char*)d->p_in; p.wproj = (const char*)d->wproj; p.w2c_ld = w2c_ld;
     p.b2b = d->b2b; p.b2c = d->b2c; p.b2a = d->b2a;

@@ -296,7 +296,7 @@ class Engine:
         s2.Hin, s2.Win, s2.C, s2.step = x.shape[1], x.shape[2], x.shape[3], fb["step"]
         return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
-    def _bneck_proj_op(self, fb, B):
+    def _bneck_proj_op(self, fb, B, keep_h1=False):
         """The FIRST block of the 64-channel stage as one launch: branch2b, then branch2c and the projection shortcut as one product
         over the K-concatenated filters of _dual_weights() (rtn_bottleneck64_fwd with p_in / wproj)."""
         wd, bd = self._dual_weights()[fb["key"]]
@@ -309,9 +309,14 @@ class Engine:
         d.w2b, d.b2b, d.w2c, d.b2c = w2b.data_ptr(), b2b.data_ptr(), wd.data_ptr(), bd.data_ptr()
         d.wproj, d.w2c_ld = wd.data_ptr() + 64 * wd.element_size(), wd.shape[1]
         d.batch, d.H, d.W, d.mid, d.dtype = B, fb["Ho"], fb["Wo"], 64, self.rdt
-        return ("bneck", d, fb["n2b"] + "+2c+1", {"xs": [a, x], "ys": [y], "B": B, "H": fb["Ho"], "W": fb["Wo"], "tail": False, "proj": True})
+        outs = [y]
+        if keep_h1:                                      # training: branch2b's activation is an input of the backward pass
+            d.h1_out, d.h1_out_elems = fb["b2"].data_ptr(), fb["b2"].numel()
+            outs.append(fb["b2"])
+        return ("bneck", d, fb["n2b"] + "+2c+1", {"xs": [a, x], "ys": outs, "B": B, "H": fb["Ho"], "W": fb["Wo"], "tail": False, "proj": True,
+                                                  "h1": keep_h1})
 
-    def _bneck_op(self, blk, nxt, B):
+    def _bneck_op(self, blk, nxt, B, keep_h1=False):
         """An identity block of the 64-channel stage as one launch (rtn_bottleneck64_fwd): branch2b + branch2c + Add + ReLU of
         `blk`, and branch2a of the following identity block `nxt` when there is one."""
         w2b, b2b = self.w[blk["n2b"]][:2]
@@ -329,8 +334,11 @@ class Engine:
             d.w2a, d.b2a = w2a.data_ptr(), b2a.data_ptr()
             outs.append(nxt["a"])
         d.batch, d.H, d.W, d.mid, d.dtype = B, blk["Ho"], blk["Wo"], 64, self.rdt
+        if keep_h1:
+            d.h1_out, d.h1_out_elems = blk["b2"].data_ptr(), blk["b2"].numel()
+            outs.append(blk["b2"])
         name = blk["n2b"] + "+2c" + ("+next2a" if nxt is not None else "")
-        return ("bneck", d, name, {"xs": [a, x], "ys": outs, "B": B, "H": blk["Ho"], "W": blk["Wo"], "tail": nxt is not None})
+        return ("bneck", d, name, {"xs": [a, x], "ys": outs, "B": B, "H": blk["Ho"], "W": blk["Wo"], "tail": nxt is not None, "h1": keep_h1})
 
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W):
@@ -414,7 +422,7 @@ class Engine:
                     if f >= 128:
                         a_acts[n2a] = a
                     if f == 64 and block > 0:
-                        blocks64.append({"block": block, "i_2a": i_2a, "i_2b": len(ops) - 1, "a": a, "x": x, "n2a": n2a, "n2b": n2b,
+                        blocks64.append({"block": block, "i_2a": i_2a, "i_2b": len(ops) - 1, "a": a, "x": x, "b2": b2, "n2a": n2a, "n2b": n2b,
                                          "n2c": "res%s%s_branch2c" % (s, bname), "Ho": Ho, "Wo": Wo})
                 if block == 0:
                     sc = buf(B, Ho, Wo, 4 * f)
@@ -512,7 +520,7 @@ class Engine:
         bneck_ok = self.dtype == "bf16" and not fp8_on
         for fs in (False, True):                         # fuse_stem
             for fd in (False, True):                     # fuse_shortcut
-                for fk in ((False, True) if bneck_ok else (False,)):      # fuse_bottleneck
+                for fk in ((0, 1, 2) if bneck_ok else (0,)):      # fuse_bottleneck: 1 = inference, 2 = training (branch2b's output is kept)
                     if not fs and not fd and not fk:
                         continue
                     v = list(ops)
@@ -523,12 +531,12 @@ class Engine:
                     if fk and fd:                            # res2a: branch2b + [branch2c | branch1] + ReLU as one launch
                         for fb in first_blocks:
                             if fb["f"] == 64 and fb["step"] == 1 and fb["i_2b"] is not None:
-                                v[fb["i_2b"]] = self._bneck_proj_op(fb, B)
+                                v[fb["i_2b"]] = self._bneck_proj_op(fb, B, keep_h1=fk == 2)
                                 v[fb["i_2c"]] = None
                     if fk:
                         for bi, blk in enumerate(blocks64):
                             nxt = blocks64[bi + 1] if bi + 1 < len(blocks64) else None      # its branch2a rides along
-                            v[blk["i_2b"]] = self._bneck_op(blk, nxt, B)
+                            v[blk["i_2b"]] = self._bneck_op(blk, nxt, B, keep_h1=fk == 2)
                             v[blk["i_2c"]] = None
                             if nxt is not None:
                                 v[nxt["i_2a"]] = None
@@ -684,7 +692,10 @@ class Engine:
         shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and filters.  The fused stem and the fused
         bottleneck exist for bf16 only; the fp8 plan keeps its own branch2a / branch2b pairing."""
         infer16 = self.dtype == "bf16" and not self.training
-        key = (self.fuse_stem and infer16, self.fuse_shortcut, self.fuse_bottleneck and infer16 and not self._fp8_on())
+        fk = 0
+        if self.fuse_bottleneck and self.dtype == "bf16" and not self._fp8_on():
+            fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
+        key = (self.fuse_stem and infer16, self.fuse_shortcut, fk)
         return key if any(key) else None
 
     def active_ops(self, plan):

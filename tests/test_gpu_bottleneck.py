@@ -49,8 +49,16 @@ def test_bottleneck64_kernel(pkg, handle, B, H, W, tail):
         d.a_out, d.a_out_elems, d.w2a, d.b2a = aout.data_ptr(), aout.numel(), wad.data_ptr(), bad.data_ptr()
     d.w2b, d.b2b, d.w2c, d.b2c = wbd.data_ptr(), bbd.data_ptr(), wcd.data_ptr(), bcd.data_ptr()
     d.batch, d.H, d.W, d.mid, d.dtype = B, H, W, 64, L.RTN_BF16
+    h1out = torch.full((B, H, W, 64), -7.0, dtype=torch.bfloat16, device=dev)
+    if H % 2:                                       # the training form: branch2b's activation is written too
+        d.h1_out, d.h1_out_elems = h1out.data_ptr(), h1out.numel()
     handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
+    if H % 2:
+        eh = float((h1out.cpu().double() - h1).abs().max())
+        assert eh <= 1e-2 * max(1.0, float(h1.abs().max())), "h1_out: max err %.3e" % eh
+    else:
+        assert torch.all(h1out == -7.0)
     got_x = xout.cpu().double()
     sx = max(1.0, float(xo.abs().max()))
     ex = float((got_x - xo).abs().max())
