@@ -291,8 +291,11 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 (void*)((EPI & 2) ? p.mask : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? p.mask_bytes : 0u)), 0x00020000);
             const int ncol = n0 + wn * 128 + 8 * lrow;
             const bool col_ok = ncol < p.N;
-            u32x4 rq[2][4], mq[2][4];               // residual / mask rows of fragment i (ping-pong: fragment i + 1 is in flight)
-            auto fetch = [&](int i, int par) {
+            // residual / mask rows of every row fragment: all MI x 4 loads of a wave go out before the first is used (these layers are
+            // bound by their pixel traffic: more loads in flight per wave; RTN_G8_EPI_DEPTH=1 at compile time: fragment i + 1 only)
+            u32x4 rq[MI][4], mq[(EPI & 2) ? MI : 1][4];
+            auto fetch = [&](int i) {
+                const int par = i, parm = (EPI & 2) ? i : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
@@ -310,13 +313,15 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                         }
                         rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? (rrow + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
                     }
-                    if (EPI & 2) mq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                    if (EPI & 2) mq[parm][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
                 }
             };
-            if (EPI) fetch(0, 0);
+            if (EPI) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fetch(i);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                if (EPI && i + 1 < MI) fetch(i + 1, (i + 1) & 1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r];
                     if (EPI) {
-                        const u32x4 rw = rq[i & 1][r], mw = mq[i & 1][r];
+                        const u32x4 rw = rq[i][r], mw = mq[(EPI & 2) ? i : 0][r];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const unsigned mj = (EPI & 2) ? mw[j] : 0x3f803f80u, rj = (EPI & 1) ? rw[j] : 0u;
