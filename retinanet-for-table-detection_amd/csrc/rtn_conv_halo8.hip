@@ -166,7 +166,7 @@ template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES 
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
     static_assert(!NB || (!STAGGER && ES == 2 && NW == 8 && !PH2), "the one-barrier step: full width bf16, no stagger");
     static_assert(!PH2 || (ES == 2 && NW == 8 && MI <= 3), "two-phase bf16 steps: full width, 192-row tiles");
-    static_assert(NW == 8 || (NW == 4 && EPI == 0 && !SPLIT), "the half-width instance has the plain bias / ReLU epilogue only");
+    static_assert(NW == 8 || (NW == 4 && !SPLIT), "the half-width instance: no column blocks / K slices");
     static_assert(ES == 2 || (ES == 1 && NW == 8 && EPI == 0 && !SPLIT), "the fp8 instance: full width, plain epilogue");
     constexpr int NBP = NW / 2;                        // 64-row pieces of a B stage
     constexpr int R = 64 * MI;                         // rows of a tile's halo image
@@ -609,12 +609,30 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     }
                 }
         } else if constexpr (NW == 4) {
-            // 4 consecutive channels per lane and row: 8-byte stores
+            // 4 consecutive channels per lane and row: 8-byte stores (and 8-byte residual / mask loads, all of a wave's in flight first)
             const H8Group& Gc = p.g[gi];
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)Gc.out, 0, (int)__builtin_amdgcn_readfirstlane((int)Gc.out_bytes), 0x00020000);
+            const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 1) ? Gc.res : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 1) ? Gc.res_bytes : 0u)), 0x00020000);
+            const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((EPI & 2) ? Gc.mask : Gc.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? Gc.mask_bytes : 0u)), 0x00020000);
             const int ncol = wn * 64 + 4 * lrow;
             const bool col_ok = ncol < p.N;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 rq[(EPI & 1) ? MI : 1][4], mq[(EPI & 2) ? MI : 1][4];
+            if (EPI) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
+                        const int m = m0 + rloc;
+                        const bool ok = col_ok && rloc < TM && m < Gc.M;
+                        if (EPI & 1) rq[i][r] = __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.res_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
+                        if (EPI & 2) mq[i][r] = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -623,11 +641,21 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     const int m = m0 + rloc;
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[i][j][r];
-                        if (p.relu) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    for (int j = 0; j < 4; ++j) v[j] = acc[i][j][r];
+                    if (EPI) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const unsigned mj = (EPI & 2) ? mq[(EPI & 2) ? i : 0][r][j] : 0x3f803f80u, rj = (EPI & 1) ? rq[(EPI & 1) ? i : 0][r][j] : 0u;
+                            const bool keep_lo = __uint_as_float(mj << 16) > 0.f, keep_hi = __uint_as_float(mj & 0xffff0000u) > 0.f;
+                            if ((EPI & 2) && p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                            if (EPI & 1) { v[2 * j] += __uint_as_float(rj << 16); v[2 * j + 1] += __uint_as_float(rj & 0xffff0000u); }
+                            if ((EPI & 2) && !p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
+                        }
                     }
-                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
                     u32x2 o;
                     o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
                     const bool ok = col_ok && rloc < TM && m < Gc.M;
@@ -762,7 +790,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (d->N <= 64 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;    // weight rows past w_rows read as zeros (descriptor range)
     if (ncb > 1 && epi) return 1;
     const bool half = d->N <= 128;                     // the 128-column instance (NW = 4): plain epilogue, no slices
-    if (half && (epi || (!forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0))) return 1;
+    if (half && !forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * es) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;
     if (((uintptr_t)d->w & 15) || ((uintptr_t)d->bias & 15)) return 1;
@@ -888,15 +916,20 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP, SP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
-#define RTN_H8_LAUNCH4(M_)                                                                               \
+#define RTN_H8_LAUNCH4E(M_, EP)                                                                          \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
         if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, 0, false, 4>,     \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, EP, false, 4>,    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
             attr_set = true;                                                                             \
         }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 4>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, EP, false, 4>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
+    } while (0)
+#define RTN_H8_LAUNCH4(M_)                                                                               \
+    do {                                                                                                 \
+        if (epi == 0) RTN_H8_LAUNCH4E(M_, 0); else if (epi == 1) RTN_H8_LAUNCH4E(M_, 1);                 \
+        else if (epi == 2) RTN_H8_LAUNCH4E(M_, 2); else RTN_H8_LAUNCH4E(M_, 3);                          \
     } while (0)
 #define RTN_H8_LAUNCH8F(M_)                                                                              \
     do {                                                                                                 \
@@ -947,6 +980,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
 #undef RTN_H8_LAUNCH_PH2
 #undef RTN_H8_LAUNCH8F
 #undef RTN_H8_LAUNCH4
+#undef RTN_H8_LAUNCH4E
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
     if (S > 1) return rtn_conv_ksplit_finish(h, ws, S, Mtot, d->N, (int)slab_ld, d->bias, p.relu, d->g[0].out, d->out_ld);

@@ -175,6 +175,7 @@ def test_dgrad_and_wgrad(pkg, handle, dtype, case):
 @pytest.mark.parametrize("impl,levels,cin,cout,k,B,grid", [
     (4, [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 3, 2, 0),     # head-tower data gradient: five levels, one grouped launch
     (4, [(40, 67)], 136, 256, 3, 3, 3),       # N = 136 gradient channels (columns 136..255 of the tile never stored), 3 workgroups
+    (4, [(40, 67), (20, 34)], 128, 128, 3, 2, 2),     # res3 branch2b data gradient: the 128-column instance (8-byte residual / mask loads)
     (5, [(25, 42)], 256, 128, 1, 8, 0),       # 1x1: gradient of a branch2c layer (K = 128 bytes x 2, N = 256)
     (5, [(33, 50)], 512, 256, 1, 2, 2),       # two N tiles, 2 workgroups walk all tiles
 ])
@@ -191,7 +192,7 @@ def test_dgrad_on_the_persistent_kernels(pkg, handle, monkeypatch, impl, levels,
     g = torch.Generator().manual_seed(300 + impl + grid)
     w = q(torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin), dtype)
     wk, rows = pack_fwd(w, dtype)
-    rows_d = 256 if impl == 4 else cin
+    rows_d = (256 if cin > 128 else 128) if impl == 4 else cin
     wd = torch.zeros(rows_d, k * k * cout, dtype=tdt, device=DEV)
     handle.check(L.lib.rtn_pack_dgrad_weights(handle.raw, wk.data_ptr(), wd.data_ptr(), code, cout, rows, k, k, cin, cout, rows_d))
     d = L.ConvDesc()
