@@ -78,6 +78,9 @@ def conv_bytes(op_desc, batch):
     return float(total)
 
 
+SECONDARY_TIMEOUT_S = 240          # multi-GPU only: see the `secondary` block of main()
+
+
 def pmc_traffic(n_conv_launches):
     """HBM bytes per step of the conv launches from the newest committed PMC summary (profiles/*pmc_traffic*.json: FETCH_SIZE x2
     + WRITE_SIZE, rocprofv3 --pmc in separate passes on this same bench command, see tools/pmc_traffic.py).  The counters are
@@ -364,10 +367,27 @@ def main():
     if not args.no_secondary:
         del eng
         torch.cuda.empty_cache()
+        # Under N ranks the training step holds collectives.  A rank that dies or diverges there would leave the others waiting in
+        # RCCL, and the inference line - measured and complete at this point - would never be printed: a timer prints it with the
+        # failure recorded and ends the process if the secondary measurement has not returned in time.
+        timer = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out["secondary"] = {"error": "training-step measurement did not return within %d s (collective stalled?)" % SECONDARY_TIMEOUT_S}
+                    print(json.dumps(out), flush=True)
+                os._exit(0 if rank == 0 else 3)
+            timer = threading.Timer(SECONDARY_TIMEOUT_S, give_up)
+            timer.daemon = True
+            timer.start()
         try:
             sec = measure_train(args.secondary_steps, min(args.warmup, 3), torch, dist, E, Wt, rank, local_rank, world, device)
         except Exception as e:          # the inference line must survive a failure here; the failure is reported, not hidden
             sec = {"error": "%s: %s" % (type(e).__name__, e)}
+        if timer is not None:
+            timer.cancel()
         if rank == 0:
             out["secondary"] = sec
     if rank == 0:
