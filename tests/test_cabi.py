@@ -66,6 +66,41 @@ def test_error_paths_without_gpu(pkg):
     assert L.lib.rtn_generate_anchors(32.0, bad, 0, bad, 1, bad) == -1
 
 
+def test_wgrad_workspace_sizes_without_gpu(pkg, monkeypatch):
+    """rtn_conv2d_wgrad_workspace_bytes is a host function: the row-info table (16 B per 64-padded pixel) plus, unless RTN_WGRAD_SLAB=0,
+    the per-split slabs of the ordered (atomic-free) reduction; the 3x3 halo kernel's slabs where it is taken (RTN_WGRAD_HALO)."""
+    L = pkg._lib
+
+    def desc(H, W, cin, cout, k, B=8):
+        d = L.ConvDesc()
+        d.ngroups, d.batch, d.dtype = 1, B, L.RTN_BF16
+        d.w_rows, d.N, d.KH, d.KW = cout, cout, k, k
+        d.Crun = d.pix_stride = cin
+        d.sy = d.sx = 1
+        d.pad_t = d.pad_l = k // 2
+        d.out_ld = cout
+        g = d.g[0]
+        g.Hin, g.Win, g.Hout, g.Wout = H, W, H, W
+        g.in_row_stride, g.in_img_stride, g.out_img_stride = W * cin, H * W * cin, H * W * cout
+        g.in_elems, g.out_elems = B * H * W * cin, B * H * W * cout
+        return d
+
+    d = desc(50, 84, 256, 64, 1)
+    table = ((8 * 50 * 84 + 63) // 64) * 64 * 16
+    monkeypatch.setenv("RTN_WGRAD_SLAB", "0")
+    monkeypatch.setenv("RTN_WGRAD_HALO", "0")
+    assert table <= L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d)) < table + 256
+    monkeypatch.setenv("RTN_WGRAD_SLAB", "1")
+    with_slabs = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+    assert with_slabs >= table + 8 * 64 * (256 + 1) * 4             # at least 8 pixel splits of [N][K] + [N] floats
+    assert (with_slabs - table) % (64 * 257 * 4) < 256               # a whole number of split slabs behind the (aligned) table
+    d3 = desc(50, 84, 256, 256, 3)                                   # res4 branch2b: the halo kernel's slabs
+    monkeypatch.setenv("RTN_WGRAD_HALO", "1")
+    halo = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3))
+    assert halo >= 16 * 256 * (9 * 256 + 1) * 4                     # 16 splits x ([N][9 C] + [N]) floats
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(None) == 0
+
+
 def test_product_does_not_import_oracle():
     pkgdir = os.path.join(ROOT, "retinanet-for-table-detection_amd")
     for dirpath, _, files in os.walk(pkgdir):
