@@ -72,11 +72,14 @@ __device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-// Store-data guard.  Observed on MI355X (ROCm 7.2): hipcc pads a 16-byte buffer store whose data registers are rewritten by the
-// next VALU instructions with the documented two wait states (s_nop 1); with the vector-memory front end backed up (this kernel
-// keeps the TA 73 % busy) the store had not yet read dword 0 of its last lanes, and the output came out corrupted in a few
-// hundred pixels per launch, differently every run.  The guard keeps the data registers live across RTN_BK_STORE_NOPS + 1 more wait
-// states (the asm statement names them as inputs), so nothing the compiler schedules can overwrite them earlier.
+// Store-data guard (root cause and machine-code excerpts: profiles/r3_store_hazard_isa.txt).  gfx940+ needs two wait states between a
+// VMEM store of more than 64 bits and a VALU write of its data VGPRs; LLVM pads them (s_nop 1) EXCEPT for buffer stores whose soffset
+// is an SGPR, which its hazard table treats as immune (GCNHazardRecognizer::createsVALUHazard).  hipcc keeps this kernel's chunk
+// offsets in SGPRs, so the x_out stores of the no-TAIL variant (whose data registers are dead after the store) were followed after
+// ZERO or one wait state by the VALU that re-used dword 0: a few hundred corrupted pixels per launch at full size, different on every
+// run.  The guard names the data registers as inputs of an `s_nop RTN_BK_STORE_NOPS`, so they stay live and unmodified for
+// RTN_BK_STORE_NOPS + 1 wait states whatever the compiler schedules; tools/scan_store_hazard.py (a CPU test) checks every 16-byte
+// store of the built library for that distance.
 #ifndef RTN_BK_STORE_NOPS
 #define RTN_BK_STORE_NOPS 3
 #endif
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 for (int u = 0; u < 2; ++u) {
                     const u32x4 ov = {h1[s][u].x, h1[s][u].y, h1[s][u].z, h1[s][u].w};
                     __builtin_amdgcn_raw_buffer_store_b128(ov, h_rsrc, (int)gc.aoff[u], s * 64, 0);
+                    BK_STORE_GUARD(ov)
                 }
         }
         // ---- G2 (branch2c + shortcut + ReLU) in four 64-channel chunks, each feeding G3 (next branch2a) as one k chunk

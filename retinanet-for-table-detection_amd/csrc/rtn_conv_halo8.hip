@@ -118,10 +118,11 @@ __device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r
     if (r >= d) { ++q; r -= d; }
 }
 
-// A 16-byte buffer store whose data registers the following VALU instructions rewrite: hipcc pads the documented two wait states,
-// which on MI355X (ROCm 7.2) is not enough when the vector-memory front end is backed up (found in rtn_bottleneck.hip: corrupted
-// dword 0 of the store's last lanes, a few hundred pixels per launch).  Naming the data registers as inputs of an asm statement
-// keeps them intact for four more wait states, whatever the compiler schedules next.
+// A 16-byte buffer store whose data registers the following VALU instructions rewrite needs two wait states on gfx940+; LLVM pads
+// them except when the store's soffset is an SGPR (its hazard table treats that form as immune), which left ZERO wait states in the
+// fused bottleneck kernel and corrupted dword 0 of such stores (profiles/r3_store_hazard_isa.txt).  Naming the data registers as
+// inputs of an asm statement keeps them intact for four wait states whatever the compiler schedules next or wherever it keeps the
+// offset; tools/scan_store_hazard.py checks the built library.
 #define RTN_STORE_GUARD(V) asm volatile("s_nop 3" :: "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w));
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {

@@ -88,7 +88,11 @@ __device__ __forceinline__ void divmod24(int f, int d, float inv, int& q, int& r
     if (r >= d) { ++q; r -= d; }
 }
 
-// see rtn_conv_halo8.hip: a 16-byte store's data registers must survive more wait states than hipcc pads
+// A 16-byte buffer store whose data registers the following VALU instructions rewrite needs two wait states on gfx940+; LLVM pads
+// them except when the store's soffset is an SGPR (its hazard table treats that form as immune), which left ZERO wait states in the
+// fused bottleneck kernel and corrupted dword 0 of such stores (profiles/r3_store_hazard_isa.txt).  Naming the data registers as
+// inputs of an asm statement keeps them intact for four wait states whatever the compiler schedules next or wherever it keeps the
+// offset; tools/scan_store_hazard.py checks the built library.
 #define RTN_STORE_GUARD(V) asm volatile("s_nop 3" :: "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w));
 #define RTN_STORE_GUARD1(V) asm volatile("s_nop 1" :: "v"(V));
 
