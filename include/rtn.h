@@ -139,9 +139,10 @@ typedef struct {
  * every forward / dgrad entry point below takes its scratch from the descriptor. */
 size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
 /* Which kernel generation the last convolution launch on this handle ran (1: 128-row register-staged, 2: 256-row LDS-DMA per tap,
- * 3: 256-row shared halo, 4: persistent 8-phase halo kernel).  For tests and profiles: proves which native path executed. */
+ * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel).  For tests and profiles: proves which native path executed. */
 int rtn_debug_last_conv_impl(rtn_handle_t h);
-/* 1 when the last weight-gradient call of this handle ran the 3x3 halo kernel (csrc/rtn_wgrad_halo.hip), 0 for the general kernels */
+/* Which weight-gradient kernel the last wgrad call of this handle ran: 1 the 3x3 halo kernel (csrc/rtn_wgrad_halo.hip), 2 the 256 x 256
+ * LDS-DMA kernel, 3 the 128 x 128 LDS-DMA kernel, 0 the register-staged kernel (fp32 and odd shapes). */
 int rtn_debug_last_wgrad_impl(rtn_handle_t h);
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
 

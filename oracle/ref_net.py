@@ -197,7 +197,37 @@ def train_step_oracle(state, images_nhwc, regression_batch, labels_batch, backbo
     yl = torch.as_tensor(np.asarray(labels_batch)).to(dtype)
     l_reg, l_cls = smooth_l1_torch(yr, reg), focal_torch(yl, cls)
     (l_reg + l_cls).backward()
-    return (float(l_reg), float(l_cls)), {k: v.grad.detach() for k, v in train.items() if v.grad is not None}
+    return (float(l_reg.detach()), float(l_cls.detach())), {k: v.grad.detach() for k, v in train.items() if v.grad is not None}
+
+
+def train_step_oracle_per_image(state, images_nhwc, regression_batch, labels_batch, backbone="resnet50", num_classes=1,
+                                dtype=torch.float64, progress=None):
+    """train_step_oracle for batches too large to hold under autograd at once (800x1333: ~7 GB per image in float64).  Same
+    mathematics: both losses are sums over anchors divided by max(1, #positive anchors of the WHOLE batch) (model/losses.py:39-44,
+    87-90), so the batch gradient is the sum of per-image gradients of (image's loss sum / batch normaliser)."""
+    net = RefNet(state, backbone, num_classes, dtype=dtype)
+    train = {k: v for k, v in net.s.items() if k.endswith("/kernel") or k.endswith("/bias")}
+    for v in train.values():
+        v.requires_grad_(True)
+    yr = torch.as_tensor(np.asarray(regression_batch)).to(dtype)
+    yl = torch.as_tensor(np.asarray(labels_batch)).to(dtype)
+    n_reg = max(1.0, float((yr[..., 4] == 1).sum()))
+    n_cls = max(1.0, float((yl[..., -1] == 1).sum()))
+    l_reg = l_cls = 0.0
+    for b in range(yr.shape[0]):
+        reg, cls = net.forward(np.asarray(images_nhwc[b:b + 1]))
+        yrb, ylb = yr[b:b + 1], yl[b:b + 1]
+        # the per-image functions divide by max(1, own positives): multiply that back and divide by the batch count
+        own_reg = max(1.0, float((yrb[..., 4] == 1).sum()))
+        own_cls = max(1.0, float((ylb[..., -1] == 1).sum()))
+        lr_b = smooth_l1_torch(yrb, reg) * (own_reg / n_reg)
+        lc_b = focal_torch(ylb, cls) * (own_cls / n_cls)
+        (lr_b + lc_b).backward()
+        l_reg += float(lr_b.detach())
+        l_cls += float(lc_b.detach())
+        if progress is not None:
+            progress(b)
+    return (l_reg, l_cls), {k: v.grad.detach() for k, v in train.items() if v.grad is not None}
 
 
 def adam_clipnorm_oracle(params, grads, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, clipnorm=0.001):

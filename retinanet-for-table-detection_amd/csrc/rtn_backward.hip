@@ -1190,7 +1190,7 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);
     RTN_CHECK_LAUNCH(h, "conv_wgrad_kernel");
-    h->last_wgrad_impl = 0;
+    h->last_wgrad_impl = dma ? 2 : dma_small ? 3 : 0;
     if (use_slab) return rtn_wgrad_finish(h, dW, p.slab, (int)w.nsplit_used, (long long)d->N * Ktot, db, p.bslab, d->N, db ? db_n : 0);
     return RTN_OK;
 }

@@ -13,7 +13,7 @@ struct rtn_ctx {
     int num_cus;
     int last_conv_impl;
          // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
-    int last_wgrad_impl;          // 1 = rtn_wgrad_halo.hip, 0 = the general kernels (rtn_debug_last_wgrad_impl)
+    int last_wgrad_impl;          // rtn_debug_last_wgrad_impl: 1 = rtn_wgrad_halo.hip, 2 = 256x256 LDS-DMA, 3 = 128x128 LDS-DMA, 0 = register-staged
     char err[512];
 };
 

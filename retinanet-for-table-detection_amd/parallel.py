@@ -27,8 +27,10 @@ class GradBucketer:
 
     segments: [(name, start, end)] in FORWARD order (element offsets into `flat`).  Buckets are contiguous runs of segments
     cut from the END of the buffer (the order backward finishes them) at about `bucket_bytes`.  layer_done(name) is called
-    right after the kernels producing that segment were enqueued; when a bucket is complete its all-reduce is issued on
-    the communication stream behind an event.  finish() issues what is left and makes the compute stream wait."""
+    right after the kernels producing that segment were enqueued, ON THE STREAM they were enqueued on (the trainer spreads the
+    weight gradients over several HIP streams): it records an event there, one per (bucket, stream) - streams are in order, so the
+    latest event of a stream covers every earlier layer on it.  When a bucket is complete its all-reduce is issued on the
+    communication stream behind ALL of the bucket's events.  finish() issues what is left and makes the compute stream wait."""
 
     def __init__(self, flat, segments, group=None, bucket_bytes=32 << 20):
         self.flat, self.group = flat, group
@@ -45,12 +47,14 @@ class GradBucketer:
         if cur:
             self.buckets.append(cur)
         self.where = {seg[0]: bi for bi, b in enumerate(self.buckets) for seg in b}
+        self._events = {}
         self.reset()
 
     def reset(self):
         self.pending = [set(seg[0] for seg in b) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.work = []
+        self.marks = [{} for _ in self.buckets]          # bucket -> {stream id: (stream, event recorded after its last layer there)}
 
     def _launch(self, bi):
         segs = self.buckets[bi]
@@ -58,18 +62,35 @@ class GradBucketer:
         view = self.flat[lo:hi]
         self.launched[bi] = True
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record()
+            marks = self.marks[bi]
+            if not marks:                                 # finish() on a bucket no layer reported: order behind the caller's stream
+                self._mark(bi)
             with torch.cuda.stream(self.comm):
-                self.comm.wait_event(ev)
+                for _, ev in marks.values():
+                    self.comm.wait_event(ev)
                 self.work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _mark(self, bi):
+        st = torch.cuda.current_stream(self.flat.device)
+        pool = self._events.setdefault((bi, st.cuda_stream), torch.cuda.Event())
+        pool.record(st)
+        self.marks[bi][st.cuda_stream] = (st, pool)
+
+    def mark(self, name):
+        """Record the current stream's progress for `name`'s bucket without completing the segment (a segment produced by
+        kernels on several streams - the fused bias gradients - is marked once per stream before layer_done)."""
+        bi = self.where.get(name)
+        if bi is not None and not self.launched[bi] and self.cuda:
+            self._mark(bi)
 
     def layer_done(self, name):
         bi = self.where.get(name)
         if bi is None or self.launched[bi]:
             return
+        if self.cuda:
+            self._mark(bi)
         self.pending[bi].discard(name)
         if not self.pending[bi]:
             self._launch(bi)

@@ -41,6 +41,8 @@ class Trainer:
         self.wgrad_lane = os.environ.get("RTN_WGRAD_LANE", "1") != "0"   # weight gradients on side HIP streams
         self.wgrad_lanes = max(1, min(self.WG_LANES, int(os.environ.get("RTN_WGRAD_LANES", "3"))))
         self._wg_stream = None
+        self.record_impls = False      # tests: {(kind, layer): kernel code} of the last backward (rtn_debug_last_*_impl)
+        self.impls = {}
         self._bind_engine_state()
 
     def _bind_engine_state(self):
@@ -458,7 +460,7 @@ class Trainer:
         # the classification tower's data gradients on one more.  Events follow the per-buffer hazards.
         main = torch.cuda.current_stream(eng.device)
         lane_on = self.wgrad_lane
-        nwg = 1 if self.bucketer is not None else self.wgrad_lanes        # DP: one lane, so a bucket's event covers its layers
+        nwg = self.wgrad_lanes        # also under DP: the bucketer records one event per (bucket, lane) and waits for all of them
         if lane_on:
             key = ("bsched", nwg)
             if key not in bp:
@@ -496,8 +498,14 @@ class Trainer:
                     bp["rowinfo"][bi] = tab
                 h.check(lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr() if b[4] is not None else None,
                                                       b[5] if b[4] is not None else 0, tab.data_ptr(), tab.numel()))
+                if self.record_impls:
+                    self.impls[("wgrad", b[3])] = lib.rtn_debug_last_wgrad_impl(h.raw)
                 if self.bucketer is not None:         # this layer's weight gradient is enqueued: its bucket may go out
                     done_names = [b[3]] + (["__biases__"] if bi == bp["last_bias_bop"] else [])   # last fused bias gradient
+                    if len(done_names) > 1 and lane_on:   # the bias gradients came from every weight-gradient lane: mark them all
+                        for ln_ in range(1, nwg + 1):
+                            with torch.cuda.stream(streams[ln_]):
+                                self.bucketer.mark("__biases__")
                     for dn in done_names:
                         if on_side:
                             with torch.cuda.stream(side):     # the bucket's event must follow the kernels on THEIR stream
@@ -506,6 +514,8 @@ class Trainer:
                             self.bucketer.layer_done(dn)
             elif kind == "dgrad":
                 h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
+                if self.record_impls:
+                    self.impls[("dgrad", b[2])] = lib.rtn_debug_last_conv_impl(h.raw)
             elif kind == "bgrad":
                 h.check(lib.rtn_bias_grad(h.raw, b[1].data_ptr(), eng.rdt, b[2], b[3], b[4], b[5].data_ptr()))
             elif kind == "padcast":

@@ -290,7 +290,7 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
         db = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
         handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
         torch.cuda.synchronize()
-        assert L.lib.rtn_debug_last_wgrad_impl(handle.raw) == (1 if halo else 0)
+        assert (L.lib.rtn_debug_last_wgrad_impl(handle.raw) == 1) == halo      # 0 / 2 / 3: the general kernels
         return dW.cpu(), db.cpu()
 
     dW1, db1 = run(True)
