@@ -276,6 +276,15 @@ int rtn_sumsq(rtn_handle_t h, const float* g, const float* scale, int64_t n, dou
 int rtn_adam_clipnorm_step(rtn_handle_t h, float* w, float* m, float* v, const float* g, const float* gscale, const float* fold,
                            void* w_fwd, int fwd_dtype, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
                            const double* sumsq, float clipnorm, float grad_mul);
+/* The same step with PER-TENSOR clipping (tf.keras / Keras >= 2.4 semantics of Adam(clipnorm=c), RetinaNet.py:130 under those
+ * versions): tensor t, the segment [seg_begin[t], seg_begin[t+1]) of the flat vector (int64 table on the device,
+ * nseg + 1 entries, at most 2048 tensors), is scaled by clipnorm / max(norm_t, clipnorm).  rtn_sumsq_segments writes the nseg sums of
+ * (g*scale)^2 in a fixed order (one workgroup per tensor); `elem_offset` is the flat index of w[0] when the step runs on a sub-range. */
+int rtn_sumsq_segments(rtn_handle_t h, const float* g, const float* scale, const int64_t* seg_begin_dev, int nseg, double* out_dev);
+int rtn_adam_clipnorm_step_segments(rtn_handle_t h, float* w, float* m, float* v, const float* g, const float* gscale, const float* fold,
+                                    void* w_fwd, int fwd_dtype, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                                    const int64_t* seg_begin_dev, int nseg, const double* sumsq_seg_dev, int64_t elem_offset,
+                                    float clipnorm, float grad_mul);
 
 /* ---- stem input packing ------------------------------------------------------------
  * NHWC C=3 image batch -> zero-padded [B][Hp][Wp][4] so that the 7x7/2 stem conv

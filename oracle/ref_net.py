@@ -230,13 +230,17 @@ def train_step_oracle_per_image(state, images_nhwc, regression_batch, labels_bat
     return (l_reg, l_cls), {k: v.grad.detach() for k, v in train.items() if v.grad is not None}
 
 
-def adam_clipnorm_oracle(params, grads, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, clipnorm=0.001):
-    """keras.optimizers.Adam with clipnorm: grads scaled by clipnorm/norm when the GLOBAL norm exceeds clipnorm."""
+def adam_clipnorm_oracle(params, grads, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7, clipnorm=0.001, global_clip=True):
+    """keras.optimizers.Adam with clipnorm (RetinaNet.py:130).  global_clip=True: standalone Keras 2.x get_gradients — every gradient
+    scaled by clipnorm/norm when the GLOBAL norm exceeds clipnorm; False: tf.keras / Keras >= 2.4 — tf.clip_by_norm per tensor."""
     norm = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
     c = clipnorm / norm if (clipnorm and norm > clipnorm) else 1.0
     lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
     out = {}
     for k, p in params.items():
+        if not global_clip and k in grads:
+            nk = math.sqrt(float((grads[k].double() ** 2).sum()))
+            c = clipnorm / nk if (clipnorm and nk > clipnorm) else 1.0
         g = grads[k].double() * c if k in grads else torch.zeros_like(p, dtype=torch.float64)
         m[k] = b1 * m.get(k, 0) + (1 - b1) * g
         v[k] = b2 * v.get(k, 0) + (1 - b2) * g * g

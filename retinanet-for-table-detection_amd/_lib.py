@@ -121,6 +121,8 @@ SIGNATURES = {
     "rtn_sumsq_workspace_bytes": (_SZ, []),
     "rtn_sumsq": (_I, [_P, _P, _P, _I64, _P, _P, _SZ]),
     "rtn_adam_clipnorm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _F, _F, _F, _F, _P, _F, _F]),
+    "rtn_sumsq_segments": (_I, [_P, _P, _P, _P, _I, _P]),
+    "rtn_adam_clipnorm_step_segments": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _F, _F, _F, _F, _P, _I, _P, _I64, _F, _F]),
     "rtn_stem_pack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I]),
     "rtn_stem_conv_pool": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I]),
     "rtn_maxpool3x3s2_tfsame_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),

@@ -958,6 +958,63 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
     }
 }
 
+// Per-tensor clipping (tf.keras / Keras >= 2.4 semantics of Adam(clipnorm=c)): every gradient tensor t is scaled by
+// c / max(||g_t||, c).  The tensors are contiguous segments [seg_begin[s], seg_begin[s + 1]) of the flat parameter vector.
+__global__ __launch_bounds__(256) void sumsq_segments_kernel(const float* __restrict__ g, const float* __restrict__ scale,
+                                                             const long long* __restrict__ seg_begin, double* __restrict__ out) {
+    const long long lo = seg_begin[blockIdx.x], hi = seg_begin[blockIdx.x + 1];
+    double s = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {               // fixed order: the same bits on every run
+        const float v = g[i] * (scale ? scale[i] : 1.f);
+        s += (double)v * (double)v;
+    }
+    __shared__ double sh[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+constexpr int ADAM_MAX_SEGS = 2048;
+template <int ES>
+__global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                            const float* __restrict__ g, const float* __restrict__ gscale,
+                                                            const float* __restrict__ fold, char* __restrict__ w_fwd, long long n, float lr_t,
+                                                            float b1, float b2, float eps, const long long* __restrict__ seg_begin, int nseg,
+                                                            const double* __restrict__ sumsq_seg, long long elem_offset, float clipnorm,
+                                                            float grad_mul) {
+    __shared__ long long sb[ADAM_MAX_SEGS + 1];
+    __shared__ float sclip[ADAM_MAX_SEGS];
+    for (int i = threadIdx.x; i <= nseg; i += 256) sb[i] = seg_begin[i];
+    for (int i = threadIdx.x; i < nseg; i += 256) {
+        const float norm = sqrtf((float)sumsq_seg[i]) * fabsf(grad_mul);
+        sclip[i] = (clipnorm > 0.f && norm > clipnorm) ? clipnorm / norm : 1.f;
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long gi_ = i + elem_offset;
+        int lo = 0, hi = nseg;                          // last segment whose begin <= gi_
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sb[mid] <= gi_) lo = mid; else hi = mid;
+        }
+        const float gi = g[i] * (gscale ? gscale[i] : 1.f) * grad_mul * sclip[lo];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float wi = w[i] - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; w[i] = wi;
+        if (w_fwd) {
+            const float wf = wi * (fold ? fold[i] : 1.f);
+            if constexpr (ES == 2) {
+                const __bf16 hb = (__bf16)wf;
+                reinterpret_cast<unsigned short*>(w_fwd)[i] = __builtin_bit_cast(unsigned short, hb);
+            } else {
+                reinterpret_cast<float*>(w_fwd)[i] = wf;
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(long long work, int cap = 4096) {
     long long g = (work + 255) / 256;
     if (g < 1) g = 1;
@@ -993,14 +1050,11 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     // -21 % on P3, but +25..40 % on the layers with ~1000 pixel tiles or fewer (res4/res5, C4/C5, P5, P6: short loops, and each
     // workgroup ends with 128 accumulator registers of output), hence the pixel-count condition.
     w.dma = es == 2 && d->N > 128 && Ktot >= 256 && w.tiles >= 2048;
-    if (const char* e = getenv("RTN_WGRAD_DMA")) {          // 0: never; 2: wherever the shape allows (tests, A/B)
-        const int v = atoi(e);
-        w.dma = v == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (w.dma && v != 0);
-    }
+    const int dma_env = rtn_env_int("RTN_WGRAD_DMA", -1);       // 0: never; 2: wherever the shape allows (tests, A/B); -1: unset
+    if (dma_env >= 0) w.dma = dma_env == 2 ? (es == 2 && d->N > 128 && Ktot >= 256) : (w.dma && dma_env != 0);
     // the same staging on the 128 x 128 tile for the other bf16 layers with whole 128-wide tiles (RTN_WGRAD_DMA_SMALL=0: register-staged kernel)
     w.dma_small = !w.dma && es == 2;                       // measured: train step 37.4 -> 36.8 ms against the register-staged kernel
-    if (const char* e = getenv("RTN_WGRAD_DMA_SMALL")) w.dma_small = w.dma_small && atoi(e) != 0;
-    if (const char* e = getenv("RTN_WGRAD_DMA")) { if (atoi(e) == 0) w.dma_small = false; }
+    if (rtn_env_int("RTN_WGRAD_DMA_SMALL", 1) == 0 || dma_env == 0) w.dma_small = false;
     w.CH = w.dma ? 256 : (es == 2 ? 128 : 64);
     const int ntn = (d->N + w.CH - 1) / w.CH;
     const long long ntk = (Ktot + w.CH - 1) / w.CH;
@@ -1011,12 +1065,12 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     // bound by the latency of its register-staged loads, not by MFMA work per byte.)
     const long long slots = (long long)(cus > 0 ? cus : 256) * (w.dma ? 1 : 2);
     long long target = slots * (w.dma_small ? 1 : 2);      // measured (RTN_WGRAD_BLOCKS sweep): one round for the 128 x 128 DMA kernel
-    if (const char* e = getenv("RTN_WGRAD_BLOCKS")) { const long long v = atoll(e); if (v >= 64 && v <= 65536) target = v; }
+    { const long long v = rtn_env_int("RTN_WGRAD_BLOCKS", 0); if (v >= 64 && v <= 65536) target = v; }
     long long nsplit = target / w.out_tiles;
     if (nsplit > w.tiles) nsplit = w.tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;
-    w.xcd_map = nsplit >= 8 && getenv("RTN_WGRAD_XCD") == nullptr;
+    w.xcd_map = nsplit >= 8 && rtn_env_int("RTN_WGRAD_XCD", -1) == -1;        // any value: off
     if (w.xcd_map) nsplit &= ~7ll;
     w.tiles_per_split = (int)((w.tiles + nsplit - 1) / nsplit);
     w.nsplit_used = (w.tiles + w.tiles_per_split - 1) / w.tiles_per_split;      // splits that own at least one pixel tile
@@ -1039,6 +1093,7 @@ static bool wgrad_takes_halo(const rtn_conv_desc_t* d, const WgradPlan& w) {
 // workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel
 // (rtn_wgrad_halo.hip) uses the same bytes for its own slabs
 extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
+    rtn_env_sync();
     if (!d || d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS || d->N < 1 || d->Crun < 1 || d->KH < 1 || d->KW < 1) return 0;
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return 0;
     const WgradPlan w = wgrad_plan(d, 256);
@@ -1077,6 +1132,7 @@ extern "C" int rtn_conv2d_wgrad_bias(rtn_handle_t h, const rtn_conv_desc_t* d, f
 
 static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes, int mode) {
     if (!h) return RTN_EINVAL;
+    rtn_env_sync();
     if (!d || (!dW && mode != 1) || !workspace) return rtn_fail(h, RTN_EINVAL, "wgrad: null argument");
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "wgrad: bad dtype");
     const int es = rtn_dtype_size(d->dtype);
@@ -1292,6 +1348,34 @@ extern "C" int rtn_adam_clipnorm_step(rtn_handle_t h, float* w, float* m, float*
     else
         hipLaunchKernelGGL((adam_kernel<4>), dim3(nb), dim3(256), 0, h->stream, w, m, v, g, gscale, fold, (char*)w_fwd, (long long)n, (float)lr_t, beta1, beta2, eps, sumsq, clipnorm, grad_mul);
     RTN_CHECK_LAUNCH(h, "adam_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_sumsq_segments(rtn_handle_t h, const float* g, const float* scale, const int64_t* seg_begin_dev, int nseg, double* out_dev) {
+    if (!h) return RTN_EINVAL;
+    if (!g || !seg_begin_dev || !out_dev || nseg < 1 || nseg > ADAM_MAX_SEGS) return rtn_fail(h, RTN_EINVAL, "sumsq_segments: bad argument (1..%d segments)", ADAM_MAX_SEGS);
+    hipLaunchKernelGGL(sumsq_segments_kernel, dim3((unsigned)nseg), dim3(256), 0, h->stream, g, scale, (const long long*)seg_begin_dev, out_dev);
+    RTN_CHECK_LAUNCH(h, "sumsq_segments_kernel");
+    return RTN_OK;
+}
+
+extern "C" int rtn_adam_clipnorm_step_segments(rtn_handle_t h, float* w, float* m, float* v, const float* g, const float* gscale,
+                                               const float* fold, void* w_fwd, int fwd_dtype, int64_t n, int64_t step, float lr, float beta1,
+                                               float beta2, float eps, const int64_t* seg_begin_dev, int nseg, const double* sumsq_seg_dev,
+                                               int64_t elem_offset, float clipnorm, float grad_mul) {
+    if (!h) return RTN_EINVAL;
+    if (!w || !m || !v || !g || n < 1 || step < 1) return rtn_fail(h, RTN_EINVAL, "adam_segments: bad argument");
+    if (!seg_begin_dev || !sumsq_seg_dev || nseg < 1 || nseg > ADAM_MAX_SEGS || elem_offset < 0) return rtn_fail(h, RTN_EINVAL, "adam_segments: bad segment table");
+    if (w_fwd && fwd_dtype != RTN_BF16 && fwd_dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "adam_segments: bad forward dtype");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    const unsigned nb = grid_for(n, 4096);
+    if (fwd_dtype == RTN_BF16)
+        hipLaunchKernelGGL((adam_segments_kernel<2>), dim3(nb), dim3(256), 0, h->stream, w, m, v, g, gscale, fold, (char*)w_fwd, (long long)n, (float)lr_t, beta1, beta2, eps,
+                           (const long long*)seg_begin_dev, nseg, sumsq_seg_dev, (long long)elem_offset, clipnorm, grad_mul);
+    else
+        hipLaunchKernelGGL((adam_segments_kernel<4>), dim3(nb), dim3(256), 0, h->stream, w, m, v, g, gscale, fold, (char*)w_fwd, (long long)n, (float)lr_t, beta1, beta2, eps,
+                           (const long long*)seg_begin_dev, nseg, sumsq_seg_dev, (long long)elem_offset, clipnorm, grad_mul);
+    RTN_CHECK_LAUNCH(h, "adam_segments_kernel");
     return RTN_OK;
 }
 

@@ -358,19 +358,17 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
 }
 
 int rtn_bneck_threads() {
-    const char* e = getenv("RTN_BNECK_THREADS");
-    return (e && atoi(e) == 768) ? 768 : 512;       // 220 VGPRs with the cross-strip prefetch: two waves per SIMD
+    return rtn_env_int("RTN_BNECK_THREADS", 512) == 768 ? 768 : 512;       // 220 VGPRs with the cross-strip prefetch: two waves per SIMD
 }
 bool rtn_bneck_rowpp(int nt) {                           // cross-strip software pipeline (RTN_BNECK_ROWPP=0: off, for the A/B)
-    const char* e = getenv("RTN_BNECK_ROWPP");
-    if (e && *e) return atoi(e) != 0;
-    return true;
+    return rtn_env_int("RTN_BNECK_ROWPP", 1) != 0;
 }
 
 }  // namespace
 
 extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d) {
     if (!h) return RTN_EINVAL;
+    rtn_env_sync();
     if (!d) return rtn_fail(h, RTN_EINVAL, "bottleneck64: null descriptor");
     if (d->dtype != RTN_BF16) return rtn_fail(h, RTN_EINVAL, "bottleneck64: bf16 only");
     if (d->mid != 64) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the fused block exists for 64 bottleneck channels (res2), got %d", d->mid);
@@ -392,7 +390,17 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
         return rtn_fail(h, RTN_EBOUNDS, "bottleneck64: a tensor is smaller than batch x H x W x channels");
     if (d->h1_out && (((uintptr_t)d->h1_out & 15) || d->h1_out_elems < M * 64 || d->h1_out == d->a_in))
         return rtn_fail(h, RTN_EINVAL, "bottleneck64: h1_out must be an aligned [M][64] tensor other than a_in");
-    if ((!proj && d->x_out == d->x_in) || d->x_out == d->a_in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: the output may not alias an input (taps of neighbouring strips)");
+    {   // no output may alias an input or another output: strips of other waves read a_in / x_in / p_in taps while this one stores
+        const void* ins[] = {d->a_in, proj ? d->p_in : d->x_in};
+        const void* outs[] = {d->x_out, d->a_out, d->h1_out};
+        for (int i = 0; i < 3; ++i) {
+            if (!outs[i]) continue;
+            for (const void* in : ins)
+                if (outs[i] == in) return rtn_fail(h, RTN_EINVAL, "bottleneck64: an output may not alias an input (taps of neighbouring strips)");
+            for (int j = i + 1; j < 3; ++j)
+                if (outs[i] == outs[j]) return rtn_fail(h, RTN_EINVAL, "bottleneck64: two outputs share a buffer");
+        }
+    }
     BkParams p;
     memset(&p, 0, sizeof(p));
     p.ain = (const char*)d->a_in; p.xin = (const char*)d->x_in; p.xout = (char*)d->x_out; p.aout = (char*)d->a_out;
@@ -404,12 +412,13 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     p.nstrips = (int)((M + 31) / 32);
     p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
     p.inv_w = 1.0f / (float)d->W;
-    { const char* e = getenv("RTN_BNECK_DBG"); p.dbg = (e && *e) ? atoi(e) : 0; }
+    p.dbg = rtn_env_int("RTN_BNECK_DBG", 0);
     // 12 waves per CU (154 VGPRs: three per SIMD) keep 1.5 x the loads of 8 in flight; RTN_BNECK_THREADS=512 for the A/B
     const int nt = rtn_bneck_threads();
     int grid = h->num_cus > 0 ? h->num_cus : 256;
     const int wgs_needed = (p.nstrips + nt / 64 - 1) / (nt / 64);
     if (grid > wgs_needed) grid = wgs_needed;
+    { const int gl = rtn_env_int("RTN_BNECK_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: several strips per wave on small inputs
 #define RTN_BK_LAUNCH(T, NTH, RP)                                                                        \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \

@@ -1292,9 +1292,30 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// Integer tuning knobs from the environment.  They stay switchable inside one process (tests and tools/ab_*.py flip them between
+// two launches), but a launch no longer pays ~30 getenv() string scans: the parsed values are cached per thread, and the cache is
+// dropped when the process environment has changed — detected by a checksum over the `environ` pointer array (setenv / putenv
+// replace the entry's pointer), one pass over ~50 pointers per rtn_env_sync() call at the top of an entry point.
+extern char** environ;
+namespace {
+struct EnvKnob { const char* name; int dflt; int value; };
+thread_local EnvKnob g_env_knobs[96];
+thread_local int g_env_nknobs = 0;
+thread_local unsigned long long g_env_stamp = 0;
+}
+void rtn_env_sync() {
+    unsigned long long st = 0x9e3779b97f4a7c15ull;
+    if (environ)
+        for (char** e = environ; *e; ++e) st = (st ^ (unsigned long long)(uintptr_t)*e) * 0x100000001b3ull;
+    if (st != g_env_stamp) { g_env_stamp = st; g_env_nknobs = 0; }
+}
 int rtn_env_int(const char* name, int dflt) {
+    for (int i = 0; i < g_env_nknobs; ++i)
+        if (g_env_knobs[i].name == name && g_env_knobs[i].dflt == dflt) return g_env_knobs[i].value;     // string literals: pointer identity
     const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
+    const int v = (e && *e) ? atoi(e) : dflt;
+    if (g_env_nknobs < 96) g_env_knobs[g_env_nknobs++] = EnvKnob{name, dflt, v};
+    return v;
 }
 
 
@@ -1305,6 +1326,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (query) *query = 0;
     if (!h) return RTN_EINVAL;
     if (!d) return rtn_fail(h, RTN_EINVAL, "conv: null descriptor");
+    rtn_env_sync();
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32 && !(d->dtype == RTN_FP8 && q8)) return rtn_fail(h, RTN_EINVAL, "conv: bad dtype %d", d->dtype);
     if (q8) {
         if (d->dtype != RTN_FP8) return rtn_fail(h, RTN_EINVAL, "conv fp8: the descriptor's dtype must be RTN_FP8");
@@ -1734,6 +1756,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
             if (ksplit < 2 || !scratch) ksplit = 1;
             p.scratch = scratch;
         }
+        if (query) return RTN_OK;                      // query mode never launches (RTN_CONV_SPLITK=0 skips the block above)
         if (ksplit > 1) {
             p.ksplit = ksplit;
             p.kt_per_split = (p.nkt + ksplit - 1) / ksplit;

@@ -791,6 +791,9 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (d->N <= 64 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;    // weight rows past w_rows read as zeros (descriptor range)
     if (ncb > 1 && epi) return 1;
     const bool half = d->N <= 128;                     // the 128-column instance (NW = 4): plain epilogue, no slices
+    // the kernel reads the bias of every column of its tile (128 or 256 per block): bias is [w_rows] by contract (rtn.h), so a layer
+    // whose N is not a whole tile (N = 192, 72, ...) is only taken when w_rows covers the tile
+    if (d->bias && d->w_rows < (half ? 128 : 256 * ncb)) return 1;
     if (half && !forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * es) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;

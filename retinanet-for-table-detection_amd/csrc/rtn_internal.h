@@ -44,8 +44,10 @@ inline int rtn_fail(rtn_ctx* h, int code, const char* fmt, ...) {
 
 // rtn_conv_halo8.hip: persistent 8-phase kernel for the stride-1 3x3 layers with 129..256 output channels (head towers, P3-P5,
 // res4 branch2b).  RTN_OK = launched, 1 = not a layer this kernel takes, < 0 = error.
-// integer environment knob, read on every call so that one process can A/B kernel variants (tools/ab_conv.py)
+// integer environment knob (name must be a string literal): cached per thread, re-read when the environment changed, so one process
+// can still A/B kernel variants (tools/ab_conv.py).  rtn_env_sync() revalidates the cache: call it at the top of an entry point.
 int rtn_env_int(const char* name, int dflt);
+void rtn_env_sync();
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
                        long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8 = nullptr);
 size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);

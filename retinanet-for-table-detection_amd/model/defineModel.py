@@ -21,10 +21,13 @@ class _LayerRef:
 
 
 class Adam:
-    """ keras.optimizers.Adam(lr, clipnorm) stand-in accepted by Model.compile (RetinaNet.py:130)."""
+    """ keras.optimizers.Adam(lr, clipnorm) stand-in accepted by Model.compile (RetinaNet.py:130).  `clipnorm` clips by the GLOBAL
+    gradient norm (standalone Keras 2.x, the reference's `import keras`); global_clipnorm=False selects the per-tensor
+    tf.clip_by_norm of tf.keras / Keras >= 2.4."""
 
-    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None, **kwargs):
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None, global_clipnorm=True, **kwargs):
         self.lr, self.beta_1, self.beta_2, self.epsilon, self.clipnorm = lr, beta_1, beta_2, epsilon, clipnorm
+        self.global_clipnorm = bool(global_clipnorm)
 
 
 class History:
@@ -89,7 +92,8 @@ class Model:
             if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
                 pg = torch.distributed.group.WORLD
             root._trainer = _rt.trainer.Trainer(self.engine(), lr=opt.lr, clipnorm=(opt.clipnorm or 0.0), beta1=opt.beta_1,
-                                                beta2=opt.beta_2, eps=opt.epsilon, process_group=pg)
+                                                beta2=opt.beta_2, eps=opt.epsilon, process_group=pg,
+                                                global_clip=getattr(opt, "global_clipnorm", True))
             tr, eng = root._trainer, root._engine
             for l in root.layers:                                 # utils.freeze / freeze_model: non-trainable layers get no update
                 if l.kind == "conv" and not l.trainable:

@@ -8,7 +8,8 @@ Mirrors what the reference gets from Keras (RetinaNet.py:125-131, 280-291):
   * every conv kernel and every FPN/head bias trains; BatchNorm is frozen (freeze_bn=True): its scale is folded into the
     forward weights, so the gradient w.r.t. the Keras kernel is fold[n] * dL/dW_folded and Adam runs on the unfolded
     master copy;
-  * clipnorm: global-norm clipping (standalone Keras 2.x semantics) — `global_clip=False` is not offered.
+  * clipnorm: global-norm clipping by default (standalone Keras 2.x semantics, what the reference's `import keras` resolves to);
+    `global_clip=False` clips every gradient tensor by its own norm (tf.keras / Keras >= 2.4 semantics).
 
 The backward graph is derived from the forward op list of engine.Engine._plan: every conv gets a wgrad (+ bias grad) and a
 dgrad per input; ReLU, residual adds, UpsampleLike+Add, C6_relu, max-pool and the stride-2 convs are handled by epilogue
@@ -31,10 +32,11 @@ def _ceil128(v):
 
 
 class Trainer:
-    WG_LANES = 3          # side streams a weight gradient may go to (each has its own row-info workspace)
+    WG_LANES = 3          # side streams a weight gradient may go to
     def __init__(self, engine, lr=1e-4, clipnorm=0.001, beta1=0.9, beta2=0.999, eps=1e-7, alpha=0.25, gamma=2.0, sigma=3.0,
-                 process_group=None):
+                 process_group=None, global_clip=True):
         self.eng = engine
+        self.global_clip = bool(global_clip)
         self.lr, self.clipnorm, self.b1, self.b2, self.eps = lr, clipnorm, beta1, beta2, eps
         self.alpha, self.gamma, self.sigma = alpha, gamma, sigma
         self.pg = process_group
@@ -102,6 +104,12 @@ class Trainer:
         self.v = torch.zeros(NW + NB, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(NW + NB, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        # per-tensor clipping: one segment per conv kernel and per bias vector (a Keras weight tensor each), in flat order
+        begins = [lo["woff"] for lo in eng.layout.values()] + [NW + lo["boff"] for lo in eng.layout.values()] + [NW + NB]
+        assert begins == sorted(begins)
+        self.seg_begin = torch.tensor(begins, dtype=torch.int64, device=dev)
+        self.nseg = len(begins) - 1
+        self.sumsq_seg = torch.zeros(self.nseg, dtype=torch.float64, device=dev)
         self.ss_ws = torch.empty(L.lib.rtn_sumsq_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.loss_sums = torch.zeros(4, dtype=torch.float64, device=dev)
         # dgrad weights (re-packed from the forward weights after every optimizer step)
@@ -338,10 +346,12 @@ class Trainer:
                 done[tid(x)] = done.get(tid(x), 0) + 1
                 bops.append(("poolbwd", x, dy, gbuf(x), op[3], op[4]))
                 gstate[tid(x)] = "buf"
-        ws = torch.empty(max(max_ws, 16), dtype=torch.uint8, device=dev)
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
         bias_bops = [i for i, b in enumerate(bops) if b[0] == "wgrad" and b[4] is not None]
-        bp = {"bops": bops, "keep": keep, "ws": ws, "last_bias_bop": bias_bops[-1] if bias_bops else -1, "ws_lanes": [ws] + [torch.empty_like(ws) for _ in range(self.WG_LANES - 1)],
+        # every weight-gradient op owns its workspace (row-info table + the slabs of its ordered split reduction: 130 MB for a head
+        # layer at batch 16 x 800 x 1333, 3.4 GB over the 107 layers), allocated at its first launch in forward_backward: ops on
+        # different lanes never share scratch, and the table is built once per layer
+        bp = {"bops": bops, "keep": keep, "last_bias_bop": bias_bops[-1] if bias_bops else -1, "wgrad_ws_bytes": max_ws,
               "d_reg": d_reg, "d_cls": d_cls, "dyp_cls": dyp_cls, "loss_ws": loss_ws, "plan": plan, "rowinfo": {}}
         self.bplans[key] = bp
         return bp
@@ -475,7 +485,6 @@ class Trainer:
             self._wg_ev.record(main)                      # side lanes start behind the loss backward and the gradient reset
             for st in streams[1:]:
                 st.wait_event(self._wg_ev)
-        ws = bp["ws"]
         for bi, b in enumerate(bp["bops"]):
             kind = b[0]
             on_side = False
@@ -488,8 +497,6 @@ class Trainer:
                 if on_side:
                     side = st
                     h.set_stream(st.cuda_stream)
-                    if 1 <= ln <= nwg:
-                        ws = bp["ws_lanes"][ln - 1]
             if kind == "wgrad":
                 tab = bp["rowinfo"].get(bi)
                 if tab is None:                       # the row-info table depends on the descriptor only: built once per layer
@@ -556,8 +563,17 @@ class Trainer:
         h.check(lib.rtn_sumsq(h.raw, self.grad.data_ptr(), self.gscale.data_ptr(), n, self.sumsq.data_ptr(), self.ss_ws.data_ptr(),
                               self.ss_ws.numel()))
         lr = self.lr if lr is None else lr
+        if not self.global_clip:
+            h.check(lib.rtn_sumsq_segments(h.raw, self.grad.data_ptr(), self.gscale.data_ptr(), self.seg_begin.data_ptr(), self.nseg,
+                                           self.sumsq_seg.data_ptr()))
         for lo_, cnt, wf, code in ((0, self.NW, eng.wflat, eng.rdt), (self.NW, self.NB, eng.bflat, L.RTN_F32)):
             off4 = lo_ * 4
+            if not self.global_clip:
+                h.check(lib.rtn_adam_clipnorm_step_segments(
+                    h.raw, self.master.data_ptr() + off4, self.m.data_ptr() + off4, self.v.data_ptr() + off4, self.grad.data_ptr() + off4,
+                    self.gscale.data_ptr() + off4, self.fold.data_ptr() + off4, wf.data_ptr(), code, cnt, self.step_count, lr, self.b1,
+                    self.b2, self.eps, self.seg_begin.data_ptr(), self.nseg, self.sumsq_seg.data_ptr(), lo_, self.clipnorm, 1.0))
+                continue
             h.check(lib.rtn_adam_clipnorm_step(h.raw, self.master.data_ptr() + off4, self.m.data_ptr() + off4, self.v.data_ptr() + off4,
                                                self.grad.data_ptr() + off4, self.gscale.data_ptr() + off4, self.fold.data_ptr() + off4,
                                                wf.data_ptr(), code, cnt, self.step_count, lr, self.b1, self.b2, self.eps,

@@ -18,9 +18,14 @@ def bf(x):
     return x.to(torch.bfloat16).to(torch.float64)
 
 
-@pytest.mark.parametrize("B,H,W,tail", [(2, 9, 13, True), (1, 40, 67, False), (3, 5, 4, True), (1, 1, 1, True), (8, 25, 42, True)])
-def test_bottleneck64_kernel(pkg, handle, B, H, W, tail):
+@pytest.mark.parametrize("B,H,W,tail,grid", [(2, 9, 13, True, 0), (1, 40, 67, False, 0), (3, 5, 4, True, 0), (1, 1, 1, True, 0), (8, 25, 42, True, 0),
+                                             # RTN_BNECK_GRID: 3-11 strips per wave, so the cross-strip software pipeline (the next
+                                             # strip's first loads issued between this strip's stores, gc = gn) runs in every form
+                                             (2, 41, 67, True, 2), (2, 41, 67, False, 2), (1, 40, 67, False, 3), (3, 33, 50, True, 5)])
+def test_bottleneck64_kernel(pkg, handle, monkeypatch, B, H, W, tail, grid):
     L = pkg._lib
+    if grid:
+        monkeypatch.setenv("RTN_BNECK_GRID", str(grid))
     g = torch.Generator().manual_seed(H * 100 + W)
     dev = torch.device("cuda")
     a = torch.relu(torch.randn(B, H, W, 64, generator=g, dtype=torch.float64))
@@ -54,6 +59,12 @@ def test_bottleneck64_kernel(pkg, handle, B, H, W, tail):
         d.h1_out, d.h1_out_elems = h1out.data_ptr(), h1out.numel()
     handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
+    if grid:                                        # several strips per wave: the result repeats bit for bit
+        first = (xout.clone(), aout.clone(), h1out.clone())
+        for rep in range(3):
+            handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
+        torch.cuda.synchronize()
+        assert torch.equal(first[0], xout) and torch.equal(first[1], aout) and torch.equal(first[2], h1out)
     if H % 2:
         eh = float((h1out.cpu().double() - h1).abs().max())
         assert eh <= 1e-2 * max(1.0, float(h1.abs().max())), "h1_out: max err %.3e" % eh
@@ -79,15 +90,25 @@ def test_bottleneck64_kernel(pkg, handle, B, H, W, tail):
     d.x_out = xd.data_ptr()
     assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1          # output aliasing the shortcut
     d.x_out = xout.data_ptr()
+    if tail:
+        d.a_out = ad.data_ptr()
+        assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1      # next-branch2a output aliasing this block's branch2a input
+        d.a_out = aout.data_ptr()
+    if H % 2:
+        d.h1_out = xout.data_ptr()
+        assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1      # two outputs in one buffer
+        d.h1_out = h1out.data_ptr()
     d.x_in_elems = xd.numel() - 1
     assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -4
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 9, 13), (1, 40, 67), (8, 25, 42), (1, 1, 1)])
-def test_bottleneck64_projection_shortcut_form(pkg, handle, B, H, W):
+@pytest.mark.parametrize("B,H,W,grid", [(2, 9, 13, 0), (1, 40, 67, 0), (8, 25, 42, 0), (1, 1, 1, 0), (2, 41, 67, 2)])
+def test_bottleneck64_projection_shortcut_form(pkg, handle, monkeypatch, B, H, W, grid):
     """The stage's first block (res2a): x_out = relu(conv1x1(h1; w2c) + conv1x1(p; wproj) + (b2c + b1)) with the K-concatenated
     [branch2c | branch1] filters of rtn_conv1x1_dual_fwd (w2c_ld = 128, wproj = w2c + 64 elements)."""
     L = pkg._lib
+    if grid:
+        monkeypatch.setenv("RTN_BNECK_GRID", str(grid))      # 11 strips per wave
     g = torch.Generator().manual_seed(H * 10 + W)
     dev = torch.device("cuda")
     a = torch.relu(torch.randn(B, H, W, 64, generator=g, dtype=torch.float64))

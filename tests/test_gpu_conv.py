@@ -428,3 +428,43 @@ def test_conv_rejects_bad_descriptors(pkg, handle):
     d.w_rows = 64                                         # not padded to 128 rows
     assert L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)) == -1
     torch.cuda.synchronize()
+
+
+def test_workspace_query_never_launches(pkg, handle, monkeypatch):
+    """rtn_conv2d_workspace_bytes is conv_launch in query mode.  With RTN_CONV_SPLITK=0 the split-K sizing block (and its early
+    return) is skipped for a tiny-M long-K layer on generation 1; the query must still return before any kernel is launched: the
+    output buffer keeps its fill value and the handle's last-kernel record does not change."""
+    L = pkg._lib
+    dev = torch.device("cuda")
+    B, H, W, cin, cout = 1, 6, 7, 2048, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(dev)
+    wk, rows = pack_w(torch.randn(1, 1, cin, cout, generator=g, dtype=torch.float64) / 45.0, "bf16", dev)
+    bk = torch.zeros(rows, dtype=torch.float32, device=dev)
+    out = torch.full((B, H, W, cout), -77.0, dtype=torch.bfloat16, device=dev)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, B, 0
+    d.w, d.bias, d.w_rows, d.N, d.KH, d.KW = wk.data_ptr(), bk.data_ptr(), rows, cout, 1, 1
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.out_ld = cout
+    grp = L.ConvGroup()
+    grp.in_, grp.in_elems, grp.in_img_stride, grp.in_row_stride = x.data_ptr(), x.numel(), H * W * cin, W * cin
+    grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+    grp.out, grp.out_elems, grp.out_img_stride = out.data_ptr(), out.numel(), H * W * cout
+    d.g[0] = grp
+    monkeypatch.setenv("RTN_CONV_IMPL", "1")
+    for splitk in ("0", "4"):
+        monkeypatch.setenv("RTN_CONV_SPLITK", splitk)
+        before = L.lib.rtn_debug_last_conv_impl(handle.raw)
+        nbytes = L.lib.rtn_conv2d_workspace_bytes(handle.raw, C.byref(d))
+        torch.cuda.synchronize()
+        assert (nbytes > 0) == (splitk == "4")
+        assert torch.all(out == -77.0), "the workspace query wrote the output (RTN_CONV_SPLITK=%s)" % splitk
+        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == before
+    # and the real launch still works with the split off
+    monkeypatch.setenv("RTN_CONV_SPLITK", "0")
+    handle.check(L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    want = (x.double().reshape(-1, cin) @ wk[:cout].double().t().cpu().to(dev)).reshape(B, H, W, cout)
+    assert float((out.double() - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max()))

@@ -7,9 +7,9 @@ on axis 0, ONE loss over the concatenated outputs - so focal and smooth-L1 are n
 WHOLE batch (model/losses.py:39-44,87-90).  One image of the batch has no ground-truth box (zero positives): a per-rank
 normaliser would be wrong for its rank, and the test checks that it would.
 
-fp32 path; stated tolerance: gradients within 1e-5 of the largest gradient element per layer group (the weight gradient's
-float atomics make the last bits run-dependent), weights after the step within 1e-3 x lr of each other, and bit-identical
-between the two ranks."""
+fp32 path; stated tolerance: gradients within 1e-5 of the largest gradient element per layer group (the two halves are summed
+in another order than the merged batch's pixel splits: fp32 association, not run-to-run noise - the weight gradients have had
+no float atomics since round 2), weights after the step within 1e-3 x lr of each other, and bit-identical between the two ranks."""
 import importlib
 import os
 import socket

@@ -9,9 +9,8 @@ the reference), see tests/test_gpu_net.py.  The device runs the whole batch; the
 FIRST and the LAST image of it (the last image's rows sit in the last, partly filled tiles of every layer).
 
 Stated tolerances, boxes in pixels of the canvas after RegressBoxes (x = anchor + 0.2 * side * delta, model/layers.py:107-150):
-  fp32 path   every decoded box within 1e-3 px (BASELINE.json north_star) on P3..P5; on P6/P7, whose anchors are up to 813 px
-              wide, within 1e-3 px + 2e-6 x anchor side (fp32 rounding of the regression value itself: one ulp of a delta of
-              magnitude 4 moves a 813 px anchor by 8e-5 px); scores within 1e-5.
+  fp32 path   every decoded box within 1e-3 px (BASELINE.json north_star) on every level, P6/P7 included (measured <= 5.0e-4 px);
+              scores within 1e-5.
   bf16 path   scores within 2e-2 of both oracles (the bf16 noise floor, test_gpu_net.py); |box drift| <= 1.5 % of the anchor side
               on every level (a regression-delta error of 7.5e-2: the drift is 0.2 x side x delta error, so it GROWS with the
               level's anchors) and, in pixels, <= 2 px on P3..P5 and <= 4 px on P6/P7, whose anchors are up to 575 / 1149 px long.
@@ -23,8 +22,9 @@ Stated tolerances, boxes in pixels of the canvas after RegressBoxes (x = anchor 
               bf16 computation whose own distance from the truth is of the same size (printed as "yardstick"), so two bf16 results can
               be 1.5 x further apart than either is from the truth: against it the bounds are 1.5 x the ones above (measured 0.62 /
               1.28 / 2.19 / 2.28 / 3.31 px), and the engine may not be further from the truth than 1.5 x the yardstick + 0.25 px.
-  ResNet-101  (configs[4], 1024x1024) bf16: within 1.5 x what torch-CPU's own bf16 emulation of that graph loses against float64
-              (that random 101-layer network amplifies rounding 4 x more than the ResNet-50 one: 2.8 px / 4 % of the side on P3);
+  ResNet-101  (configs[4], 1024x1024) bf16: absolute bounds 4.5 / 7.5 / 11.5 / 16 / 25 px on P3..P7, 7 % of the anchor side, scores
+              6.5e-2, regression rms 0.06 (that random 101-layer network amplifies rounding 4 x more than the ResNet-50 one: torch-CPU's
+              own bf16 emulation of the graph, the yardstick, loses 2.8 px / 4 % of the side on P3), and within 1.5 x the yardstick;
               fp8 plan (towers + backbone 3x3 + P3 in e4m3) against the FLOAT64 oracle: regression relative RMS <= 0.10, score
               rms <= 0.06 / max <= 0.45, box drift <= 0.5 of the anchor side (measured 0.080, 0.35 max, 0.42): what 39 e4m3 layers in
               a row cost on random filters, stated as such.
@@ -146,8 +146,7 @@ def test_r50_800x1333_fp32_within_1e3_px(pkg, r50_case):
         rows, dcls = drift_report("fp32 image %d vs float64 oracle" % b, reg[i], cls[i], oreg, ocls, c["canvas"])
         assert dcls <= 1e-5
         for lv, dpx, dfrac, smax in rows:
-            bound = 1e-3 if lv <= 5 else 1e-3 + 2e-6 * smax
-            assert dpx <= bound, "P%d: %.3e px > %.3e" % (lv, dpx, bound)
+            assert dpx <= 1e-3, "P%d: %.3e px > 1e-3 (BASELINE.json north_star)" % (lv, dpx)          # measured <= 5.0e-4 on every level
 
 
 @pytest.fixture(scope="module")
@@ -183,13 +182,19 @@ def test_r101_1024_bf16_and_fp8_against_the_float64_oracle(pkg, r101_case):
     # the device stays within 1.5 x that yardstick on every level.
     yrows, ycls = drift_report("R101 yardstick: torch-CPU bf16 emulation vs float64", c["oemu"][0], c["oemu"][1], oreg, ocls, c["canvas"])
     rows, dcls = drift_report("R101 bf16 vs float64 oracle", reg[0].cpu().numpy(), cls[0].cpu().numpy(), oreg, ocls, c["canvas"])
-    assert dcls <= 1.5 * ycls
+    # ABSOLUTE bounds (what the yardstick measured on MI355X's host, x 1.6, written out): box drift <= 4.5 / 7.5 / 11.5 / 16 / 25 px
+    # on P3..P7 and <= 7 % of the anchor side on every level, scores <= 6.5e-2, regression rms <= 0.06.  Measured: yardstick 2.83 /
+    # 4.64 / 7.08 / 10.5 / 15.7 px (4.6 % of the side at most), scores 4.2e-2, rms 0.045; device 2.5-2.7 / 4.9-5.1 / 6.7-7.8 / 9.8-10.4 /
+    # 11.2-16.4 px, 4.2-4.3e-2, 0.044.  The relative check against the yardstick of THIS run stays beside them.
+    ABS_PX = {3: 4.5, 4: 7.5, 5: 11.5, 6: 16.0, 7: 25.0}
+    assert dcls <= 6.5e-2 and dcls <= 1.5 * ycls
     for (lv, dpx, dfrac, _), (_, ypx, yfrac, _) in zip(rows, yrows):
+        assert dpx <= ABS_PX[lv] and dfrac <= 7e-2, "P%d drifts %.3f px = %.3e of the anchor side" % (lv, dpx, dfrac)
         assert dpx <= 1.5 * ypx and dfrac <= 1.5 * yfrac, "P%d drifts %.3f px (yardstick %.3f)" % (lv, dpx, ypx)
     rms_dev = float(np.sqrt(((reg[0].cpu().numpy() - oreg) ** 2).mean()))
     rms_emu = float(np.sqrt(((c["oemu"][0] - oreg) ** 2).mean()))
     print("R101 regression rms error: device %.5f, emulation %.5f" % (rms_dev, rms_emu))
-    assert rms_dev <= 1.25 * rms_emu
+    assert rms_dev <= 0.06 and rms_dev <= 1.25 * rms_emu
     rows_bf16 = rows
     # ---- fp8 plan
     eng.calibrate_fp8([xd], backbone=True)

@@ -191,3 +191,51 @@ def test_training_steps_repeat_bit_for_bit(pkg, dtype):
     assert a[0] == b[0], (a[0], b[0])
     for i, what in ((1, "gradient"), (2, "master weights"), (3, "first moment"), (4, "second moment")):
         assert torch.equal(a[i], b[i]), "%s differs between two identical runs (max %.3e)" % (what, float((a[i] - b[i]).abs().max()))
+
+
+def test_per_tensor_clipnorm_switch(pkg):
+    """Adam(clipnorm=0.001) clips by the global norm under standalone Keras 2.x (the default here) and per tensor under
+    tf.keras / Keras >= 2.4 (RetinaNet.py:130 does not pin the version).  Trainer(global_clip=False): every kernel / bias tensor is
+    scaled by clipnorm / max(its own norm, clipnorm) - checked against the float64 restatement on the device's own gradient, so that
+    only the optimizer differs: first-step moves within 5 % of lr, and visibly different from the global-norm step."""
+    E, Wt, T = mods(pkg)
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    x, reg_t, lab_t = make_batch(2, seed=11)
+    xd, regd, labd = torch.as_tensor(x).cuda(), torch.as_tensor(reg_t).cuda(), torch.as_tensor(lab_t).cuda()
+    params = {k: torch.as_tensor(np.asarray(v)) for k, v in state.items() if k.endswith("/kernel") or k.endswith("/bias")}
+    moves = {}
+    for global_clip in (True, False):
+        eng = E.Engine("resnet50", 1, 9, dtype="f32")
+        eng.load_state(state)
+        tr = T.Trainer(eng, lr=1e-4, clipnorm=0.001, global_clip=global_clip)
+        tr.forward_backward(xd, regd, labd)
+        torch.cuda.synchronize()
+        grads = {}
+        for name in LAYERS:
+            gk, gb = unpack_grad(tr, Wt, name)
+            grads[name + "/kernel"] = gk
+            if eng.layout[name]["has_bias"]:
+                grads[name + "/bias"] = gb
+        sub = {k: params[k] for k in grads}
+        want, _ = adam_clipnorm_oracle(sub, grads, {}, {}, 1, global_clip=False)      # compared below for the per-tensor run only
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        for name in LAYERS:
+            lo = eng.layout[name]
+            wm = tr.master[lo["woff"]:lo["woff"] + lo["rows"] * lo["K"]].view(lo["rows"], lo["K"]).cpu().double()
+            cout = lo["cout"]
+            if name == "conv1":
+                k = wm[:cout].reshape(cout, 8, 8, 4)[:, :7, :7, :3].permute(1, 2, 3, 0)
+            else:
+                k = wm[:cout].reshape(cout, lo["kh"], lo["kw"], lo["cin"]).permute(1, 2, 3, 0)
+            move = k - params[name + "/kernel"].double()
+            moves[(global_clip, name)] = move
+            if not global_clip:                        # per tensor: the oracle on a subset of tensors is the oracle on all of them
+                want_move = want[name + "/kernel"] - params[name + "/kernel"].double()
+                assert float((move - want_move).abs().max()) <= 0.05 * 1e-4, name
+                if lo["has_bias"]:
+                    bm = tr.master[tr.NW + lo["boff"]:tr.NW + lo["boff"] + cout].cpu().double() - params[name + "/bias"].double()
+                    assert float((bm - (want[name + "/bias"] - params[name + "/bias"].double())).abs().max()) <= 0.05 * 1e-4, name
+    # Adam's first step has magnitude ~lr whatever the clip factor is, but elements with |g| near eps move differently: the two
+    # semantics must not be the same code path
+    assert any(float((moves[(True, n)] - moves[(False, n)]).abs().max()) > 0 for n in LAYERS)

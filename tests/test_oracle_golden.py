@@ -148,3 +148,27 @@ def test_loss_gradients_match_finite_differences():
             pm = pred.copy(); pm[0, i, j] -= eps
             fd = (R.smooth_l1_loss(reg_t, pp)[0] - R.smooth_l1_loss(reg_t, pm)[0]) / (2 * eps)
             assert abs(fd - g[0, i, j]) < 1e-5 * max(1, abs(fd))
+
+
+def test_per_image_training_oracle_equals_the_batched_one():
+    """oracle/ref_net.train_step_oracle_per_image (used at 800x1333, where one float64 autograd graph per batch does not fit) is the
+    same mathematics as train_step_oracle: merged-batch normalisers, per-image backward passes summed.  Batch of 3 with an image
+    without any ground-truth box."""
+    import importlib
+    import torch
+    from oracle import ref_numpy as R
+    from oracle.ref_net import train_step_oracle, train_step_oracle_per_image
+    Wt = importlib.import_module("retinanet-for-table-detection_amd.weights")
+    canvas = (64, 96)
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    x = np.random.RandomState(0).uniform(-1, 1, (3,) + canvas + (3,)).astype(np.float32)
+    anchors = R.anchors_for_shape(canvas + (3,))
+    gts = [np.array([[10., 10., 60., 50.]]), np.zeros((0, 4)), np.array([[30., 20., 90., 60.], [5., 5., 40., 30.]])]
+    reg, lab = R.anchor_targets(anchors, [canvas] * 3, gts, [np.zeros(len(g)) for g in gts], 1)
+    a = train_step_oracle(state, x, reg, lab)
+    b = train_step_oracle_per_image(state, x, reg, lab)
+    assert abs(a[0][0] - b[0][0]) <= 1e-12 * abs(a[0][0]) and abs(a[0][1] - b[0][1]) <= 1e-12 * abs(a[0][1])
+    assert set(a[1]) == set(b[1])
+    for k in a[1]:
+        scale = float(a[1][k].abs().max())
+        assert float((a[1][k] - b[1][k]).abs().max()) <= 1e-12 * max(scale, 1e-30), k
