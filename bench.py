@@ -305,6 +305,10 @@ def main():
                 return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + (256 * 64 if (m["tail"] or m.get("proj")) else 0))
             return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
         flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
+        stem_op = [op for op in active if op[0] == "stem"]
+        stem_2a = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "res2a_branch2a"] if (stem_op and len(stem_op[0]) > 7) else []
+        if stem_2a:                                                    # res2a_branch2a runs inside the stem kernel: its FLOPs still count
+            flops_step += conv_flops(stem_2a[0][1], BATCH)
         ms_per_step = 1e3 * elapsed / args.steps
         achieved = flops_step / (ms_per_step * 1e-3) / 1e12
         reps = 3
@@ -336,6 +340,8 @@ def main():
         if fused_stem:                                                 # image in (bf16, 3 ch), pooled tensor out, filters
             H1, W1 = (CANVAS[0] - 1) // 2 + 1, (CANVAS[1] - 1) // 2 + 1
             bytes_step += BATCH * (CANVAS[0] * CANVAS[1] * 3 * 2 + ((H1 + 1) // 2) * ((W1 + 1) // 2) * 64 * 2) + 64 * 256 * 2
+            if stem_2a:                                                # + the branch2a tensor out, its filters in
+                bytes_step += BATCH * ((H1 + 1) // 2) * ((W1 + 1) // 2) * 64 * 2 + 64 * 64 * 2
         traffic, traffic_note = pmc_traffic(n_launch)
         roofline = {"bound": "mfma", "kernel": "all conv launches of a step (implicit-GEMM MFMA kernels, bf16)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS,

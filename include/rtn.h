@@ -305,6 +305,12 @@ int rtn_stem_pack(rtn_handle_t h, const void* src, int src_dtype, void* dst, int
  * the same order, one bf16 rounding of the ReLU output; the 34 MB/image conv1 tensor never reaches HBM. */
 int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
                        const float* bias, void* out, int B, int H, int W);
+/* The same kernel with the first bottleneck's branch2a appended (keras_resnet res2a_branch2a 1x1 64 -> 64 + bn2a_branch2a + ReLU,
+ * model/defineModel.py:376-380): a_out [B][H2][W2][64] bf16 = relu(w2a . pool1 + b2a), computed from the pooled pixels while they
+ * are in registers.  w2a: [>= 64][64] bf16 K-contiguous (BN folded), b2a: f32 [64].  `out` (pool1) is still written: the block's
+ * projection shortcut reads it. */
+int rtn_stem_conv_pool_branch2a(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
+                                const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out);
 
 /* ---- MaxPool 3x3 / 2, TF 'same' (keras_resnet pool1; -inf padding) ----------------- */
 int rtn_maxpool3x3s2_tfsame_fwd(rtn_handle_t h, const void* in, void* out, int dtype,

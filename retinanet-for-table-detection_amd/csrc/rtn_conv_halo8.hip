@@ -295,7 +295,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     float bias8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
-    if (p.bias) {
+    if (!SPLIT && p.bias && wn * (16 * NW) + NW * lrow < p.N) {     // columns past N (N = 192 on the 256-column tile, ...): zero, never read
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + wn * (16 * NW) + NW * lrow);
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
         if (NW == 8) {
@@ -791,9 +791,6 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (d->N <= 64 || ncb > 8 || d->w_rows < d->N || d->N % 8 || d->out_ld % 8) return 1;    // weight rows past w_rows read as zeros (descriptor range)
     if (ncb > 1 && epi) return 1;
     const bool half = d->N <= 128;                     // the 128-column instance (NW = 4): plain epilogue, no slices
-    // the kernel reads the bias of every column of its tile (128 or 256 per block): bias is [w_rows] by contract (rtn.h), so a layer
-    // whose N is not a whole tile (N = 192, 72, ...) is only taken when w_rows covers the tile
-    if (d->bias && d->w_rows < (half ? 128 : 256 * ncb)) return 1;
     if (half && !forced && rtn_env_int("RTN_CONV_H8_HALF", 1) == 0) return 1;
     if (d->Crun != d->pix_stride || (d->Crun * es) % 128 || d->Crun <= 0) return 1;
     if (d->pad_l < 0 || d->pad_l >= d->KW || d->pad_t < 0 || d->pad_t >= d->KH) return 1;

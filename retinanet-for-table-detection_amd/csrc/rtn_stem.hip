@@ -8,6 +8,8 @@
 // range-checked buffer loads) once, reads MFMA A fragments straight out of it (the 64-byte run of a kernel row for output x starts at pixel 2x: always
 // 16-byte aligned), multiplies the 9 x 33 conv outputs the tile's pooling windows need (halo recomputed: 1.16x), and pools
 // them from LDS.  HBM traffic: the image in, the pooled tensor out.
+// Round 3: persistent workgroups (filters resident in LDS, next patch prefetched into registers) and, optionally, the first 1x1
+// convolution of the network (res2a_branch2a + BN + ReLU) applied to the pooled pixels before they leave the registers.
 #include "rtn_internal.h"
 
 namespace {
@@ -27,8 +29,10 @@ constexpr int PA_BYTES = PA_H * PA_ROW;             // 13248
 constexpr int W_ROW = 7 * 64 + 16;                  // 7 kernel rows x 64 B per output channel, +16 B: conflict-free b128 reads
 constexpr int W_BYTES = 64 * W_ROW;                 // 29696
 constexpr int CV_PX = 144;                          // conv tile: 64 ch bf16 per pixel + 16 B (conflict-free 8-byte writes)
-constexpr int CV_BYTES = CT_N * CV_PX;              // aliases patch + weights
-constexpr int LDS_BYTES = (PA_BYTES + W_BYTES) > CV_BYTES ? (PA_BYTES + W_BYTES) : CV_BYTES;
+constexpr int CV_BYTES = CT_N * CV_PX;              // aliases the patch (dead after the MFMAs); the filters stay resident
+constexpr int LDS_BYTES = W_BYTES + (PA_BYTES > CV_BYTES ? PA_BYTES : CV_BYTES);      // 72,464 B: two workgroups per CU
+constexpr int W2A_ROW = 128 + 16;                   // branch2a filters: 64 (permuted) rows x 128 B, +16 B: conflict-free b128 reads
+constexpr int LDS_BYTES_A2 = LDS_BYTES + 64 * W2A_ROW;                                 // 81,680 B: still two per CU (163,360 of 163,840)
 
 __device__ __forceinline__ unsigned short to_bf16(float f) {
     const __bf16 hb = (__bf16)f;
@@ -37,150 +41,282 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__global__ __launch_bounds__(256) void stem_fused_kernel(const char* __restrict__ xp /* [B][Hp][Wp][4] bf16 */, unsigned xp_bytes,
-                                                         const char* __restrict__ wk /* [>=64][512 B] */,
-                                                         const float* __restrict__ bias, unsigned short* __restrict__ out,
-                                                         int Hp, int Wp, int H1, int W1, int H2, int W2, int pool_pt, int pool_pl) {
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    char* patch = lds;
-    char* wl = lds + PA_BYTES;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.z;
-    const int py0 = blockIdx.y * PT_H, px0 = blockIdx.x * PT_W;
-    const int cy0 = 2 * py0 - pool_pt, cx0 = 2 * px0 - pool_pl;        // first conv row / column of the tile
-    // conv output (cy, cx) reads packed rows 2cy .. 2cy+6 and packed pixels 2cx .. 2cx+7
-    const long long pbase = (((long long)b * Hp + 2 * cy0) * Wp + 2 * cx0) * 8;   // may be negative (tile starts at conv row/col -1)
+struct StemParams {
+    const char* xp;             // [B][Hp][Wp][4] bf16
+    const char* wk;             // [>= 64][512 B]
+    const float* bias;
+    unsigned short* out;        // pool1 [B][H2][W2][64] bf16
+    const char* w2a;            // A2: res2a_branch2a filters [>= 64][64] bf16 (BN folded), K-contiguous
+    const float* b2a;           // A2: its folded BN shift [64]
+    unsigned short* a_out;      // A2: [B][H2][W2][64] bf16
+    unsigned xp_bytes;
+    int Hp, Wp, H1, W1, H2, W2, pool_pt, pool_pl;
+    int tiles_x, tiles_y, ntiles;
+};
 
-    // ---- stage the weights (64 channels x 7 kernel rows x 64 B) and the input patch (23 rows x 36 chunks of 16 B).
-    // Out-of-buffer chunks read as zeros (range-checked buffer loads); chunks that wrap into a neighbouring row only feed
-    // conv outputs outside the image, which the pooling ignores.
+// MFMA row (16 f + 4 q + r) of the branch2a product -> output channel 32 (f >> 1) + 8 q + 4 (f & 1) + r: two accumulator fragments
+// of a lane are then 8 consecutive channels of its pixel (the permutation of rtn_bottleneck.hip)
+__device__ __forceinline__ int stem_perm_row(int rho) {
+    const int f = rho >> 4, q = (rho >> 2) & 3, r = rho & 3;
+    return 32 * (f >> 1) + 8 * q + 4 * (f & 1) + r;
+}
+
+// PERSISTENT: two workgroups per CU walk the 4 x 16 pooled tiles of the batch; the filters are staged into LDS once per workgroup
+// (they were 30 KB per tile: 250 MB of L2 reads per batch of 8), the next tile's input patch is requested into registers before
+// this tile's MFMAs and written to LDS after this tile's pooling.  A2: the pooled pixels (8 channels per lane, which is exactly a
+// B-operand fragment of the transposed product) also go through res2a_branch2a (1x1, 64 -> 64, BN, ReLU; keras_resnet bottleneck
+// behind model/defineModel.py:376-380): the layer's launch and its read of pool1 disappear.
+template <bool A2>
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* wl = lds;                      // filters, resident
+    char* patch = lds + W_BYTES;         // input patch of the tile; after the MFMAs the conv tile takes its place
+    char* cv = patch;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+    constexpr int PCH = PA_H * (PA_ROW / 16);             // 828 chunks of 16 B per patch
+    constexpr int NPF = (PCH + 255) / 256;                // 4 per thread
+    constexpr int KH_UNROLL = A2 ? 1 : 7;
+
     for (int i = t; i < 64 * 28; i += 256) {
         const int n = i / 28, q = i - n * 28;
-        *reinterpret_cast<uint4*>(wl + n * W_ROW + q * 16) = *reinterpret_cast<const uint4*>(wk + (long long)n * 512 + q * 16);
+        *reinterpret_cast<uint4*>(wl + n * W_ROW + q * 16) = *reinterpret_cast<const uint4*>(p.wk + (long long)n * 512 + q * 16);
     }
-    {
-        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xp), (short)0, (int)xp_bytes, 0x00020000);
-        for (int i = t; i < PA_H * (PA_ROW / 16); i += 256) {
-            const int r = i / (PA_ROW / 16), q = i - r * (PA_ROW / 16);
-            const long long off = pbase + (long long)r * Wp * 8 + q * 16;
-            const unsigned voff = (off >= 0 && off + 16 <= (long long)xp_bytes) ? (unsigned)off : 0xFFFFFF00u;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, (int)voff, 0, 0);
-            *reinterpret_cast<u32x4*>(patch + r * PA_ROW + q * 16) = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- 7 x (A fragment straight from the patch) x (4 channel blocks).  Operands swapped (D = W . X^T): a lane ends up with
-    // 4 consecutive channels of ONE conv pixel, which it can write as 8 bytes.
-    const int m = lane & 15, kq = lane >> 4;
-    int abase[SUB_PER_WAVE];
-#pragma unroll
-    for (int s = 0; s < SUB_PER_WAVE; ++s) {
-        int i = (wave * SUB_PER_WAVE + s) * 16 + m;
-        if (i >= CT_N) i = 0;                                           // rows past the tile: computed, never stored
-        const int ly = i / CT_W, lx = i - ly * CT_W;
-        abase[s] = (2 * ly) * PA_ROW + (2 * lx) * 8 + kq * 16;
-    }
-    f32x4 acc[SUB_PER_WAVE][4];
-#pragma unroll
-    for (int s = 0; s < SUB_PER_WAVE; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[s][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
-        uint4 bf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(wl + (j * 16 + m) * W_ROW + kh * 64 + kq * 16);
-#pragma unroll
-        for (int s = 0; s < SUB_PER_WAVE; ++s) {
-            const uint4 af = *reinterpret_cast<const uint4*>(patch + abase[s] + kh * PA_ROW);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[s][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af),
-                                                                    acc[s][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();                                                    // patch and weights are dead: the conv tile takes their place
-
-    // ---- bias + ReLU -> bf16 conv tile in LDS; positions outside the conv image become -inf for the pooling.
-    // acc[s][j][r] = conv pixel (subtile s, row m), channel j*16 + kq*4 + r
     float bn[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bn[j][r] = bias ? bias[j * 16 + kq * 4 + r] : 0.f;
-#pragma unroll
-    for (int s = 0; s < SUB_PER_WAVE; ++s) {
-        const int i = (wave * SUB_PER_WAVE + s) * 16 + m;
-        if (i >= CT_N) continue;
-        const int ly = i / CT_W, lx = i - ly * CT_W;
-        const bool inside = (unsigned)(cy0 + ly) < (unsigned)H1 && (unsigned)(cx0 + lx) < (unsigned)W1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint2 o;
-            if (inside) {
-                o.x = (unsigned)to_bf16(fmaxf(acc[s][j][0] + bn[j][0], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][1] + bn[j][1], 0.f)) << 16);
-                o.y = (unsigned)to_bf16(fmaxf(acc[s][j][2] + bn[j][2], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][3] + bn[j][3], 0.f)) << 16);
-            } else {
-                o.x = o.y = 0xFF80FF80u;
-            }
-            *reinterpret_cast<uint2*>(lds + i * CV_PX + j * 32 + kq * 8) = o;
+        for (int r = 0; r < 4; ++r) bn[j][r] = p.bias ? p.bias[j * 16 + kq * 4 + r] : 0.f;
+    // A2: the branch2a filters in LDS behind the conv tile, rows already permuted: row rho holds filter perm(rho); the shifts of
+    // this lane's accumulator rows in registers
+    char* w2l = lds + LDS_BYTES;
+    float ba[A2 ? 4 : 1][4];
+    if (A2) {
+        for (int i = t; i < 64 * 8; i += 256) {
+            const int rho = i >> 3, q = i & 7;
+            *reinterpret_cast<uint4*>(w2l + rho * W2A_ROW + q * 16) = *reinterpret_cast<const uint4*>(p.w2a + (stem_perm_row(rho) * 64 + q * 8) * 2);
         }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ba[f][r] = p.b2a[stem_perm_row(16 * f + 4 * kq + r)];
     }
-    __syncthreads();
 
-    // ---- 3x3/2 max over the tile: one thread = 8 channels of one pooled pixel
-    for (int it = t; it < PT_H * PT_W * 8; it += 256) {
-        const int cg = it & 7, pp = it >> 3;
-        const int ppy = pp / PT_W, ppx = pp - ppy * PT_W;
-        const int py = py0 + ppy, px = px0 + ppx;
-        if (py >= H2 || px >= W2) continue;
-        float mx[8];
+    // workgroup -> tiles: workgroup b runs on XCD b % 8; every XCD walks a contiguous range of tiles (neighbouring tiles share
+    // their halo columns / rows through ONE L2)
+    int tile, tile_end, tstep;
+    {
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x, xcd = bid & 7, idx = bid >> 3;
+        const int wgs = nwg / 8 + (xcd < (nwg & 7) ? 1 : 0);
+        const int lo = (int)((long long)p.ntiles * xcd / 8), hi = (int)((long long)p.ntiles * (xcd + 1) / 8);
+        tile = lo + idx; tile_end = hi; tstep = wgs > 0 ? wgs : 1;
+    }
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.xp), (short)0, (int)p.xp_bytes, 0x00020000);
+    u32x4 pf[NPF];
+    auto tile_geo = [&](int T, int& b, int& py0, int& px0) {
+        const int tx = T % p.tiles_x, r = T / p.tiles_x;
+        b = r / p.tiles_y;
+        py0 = (r - b * p.tiles_y) * PT_H;
+        px0 = tx * PT_W;
+    };
+    auto request = [&](int T) {                           // the input patch of tile T -> registers (range-checked: zeros outside)
+        int b, py0, px0;
+        tile_geo(T < p.ntiles ? T : 0, b, py0, px0);
+        const int cy0 = 2 * py0 - p.pool_pt, cx0 = 2 * px0 - p.pool_pl;
+        const long long pbase = (((long long)b * p.Hp + 2 * cy0) * p.Wp + 2 * cx0) * 8;   // may be negative (conv row / column -1)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+        for (int u = 0; u < NPF; ++u) {
+            const int i = t + 256 * u;
+            const int r = i / (PA_ROW / 16), q = i - r * (PA_ROW / 16);
+            const long long off = pbase + (long long)r * p.Wp * 8 + q * 16;
+            const bool ok = i < PCH && T < tile_end && off >= 0 && off + 16 <= (long long)p.xp_bytes;
+            pf[u] = __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(ok ? (unsigned)off : 0xFFFFFF00u), 0, 0);
+        }
+    };
+    request(tile);
+#pragma unroll 1
+    for (; tile < tile_end; tile += tstep) {
+        int b, py0, px0;
+        tile_geo(tile, b, py0, px0);
+        const int cy0 = 2 * py0 - p.pool_pt, cx0 = 2 * px0 - p.pool_pl;        // first conv row / column of the tile
+        // conv output (cy, cx) reads packed rows 2cy .. 2cy+6 and packed pixels 2cx .. 2cx+7.  Chunks that wrap into a neighbouring
+        // row only feed conv outputs outside the image, which the pooling ignores.
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int u = 0; u < NPF; ++u) {
+            const int i = t + 256 * u;
+            if (i < PCH) *reinterpret_cast<u32x4*>(patch + (i / (PA_ROW / 16)) * PA_ROW + (i % (PA_ROW / 16)) * 16) = pf[u];
+        }
+        __syncthreads();
+        request(tile + tstep);                            // in flight under this tile's MFMAs and pooling
+
+        // ---- 7 x (A fragment straight from the patch) x (4 channel blocks).  Operands swapped (D = W . X^T): a lane ends up with
+        // 4 consecutive channels of ONE conv pixel, which it can write as 8 bytes.
+        int abase[SUB_PER_WAVE];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int i = (2 * ppy + dy) * CT_W + 2 * ppx + dx;
-                const uint4 q = *reinterpret_cast<const uint4*>(lds + i * CV_PX + cg * 16);
-                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+        for (int s = 0; s < SUB_PER_WAVE; ++s) {
+            int i = (wave * SUB_PER_WAVE + s) * 16 + m;
+            if (i >= CT_N) i = 0;                                           // rows past the tile: computed, never stored
+            const int ly = i / CT_W, lx = i - ly * CT_W;
+            abase[s] = (2 * ly) * PA_ROW + (2 * lx) * 8 + kq * 16;
+        }
+        f32x4 acc[SUB_PER_WAVE][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    mx[2 * e] = fmaxf(mx[2 * e], __uint_as_float(w4[e] << 16));
-                    mx[2 * e + 1] = fmaxf(mx[2 * e + 1], __uint_as_float(w4[e] & 0xffff0000u));
+        for (int s = 0; s < SUB_PER_WAVE; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[s][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll KH_UNROLL     // A2: the fully unrolled loop hoists all 28 filter fragments and spills beside the branch2a state
+        for (int kh = 0; kh < 7; ++kh) {
+            uint4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(wl + (j * 16 + m) * W_ROW + kh * 64 + kq * 16);
+#pragma unroll
+            for (int s = 0; s < SUB_PER_WAVE; ++s) {
+                const uint4 af = *reinterpret_cast<const uint4*>(patch + abase[s] + kh * PA_ROW);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[s][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af),
+                                                                        acc[s][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                    // the patch is dead: the conv tile takes its place
+
+        // ---- bias + ReLU -> bf16 conv tile in LDS; positions outside the conv image become -inf for the pooling.
+        // acc[s][j][r] = conv pixel (subtile s, row m), channel j*16 + kq*4 + r
+#pragma unroll
+        for (int s = 0; s < SUB_PER_WAVE; ++s) {
+            const int i = (wave * SUB_PER_WAVE + s) * 16 + m;
+            if (i >= CT_N) continue;
+            const int ly = i / CT_W, lx = i - ly * CT_W;
+            const bool inside = (unsigned)(cy0 + ly) < (unsigned)p.H1 && (unsigned)(cx0 + lx) < (unsigned)p.W1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 o;
+                if (inside) {
+                    o.x = (unsigned)to_bf16(fmaxf(acc[s][j][0] + bn[j][0], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][1] + bn[j][1], 0.f)) << 16);
+                    o.y = (unsigned)to_bf16(fmaxf(acc[s][j][2] + bn[j][2], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][3] + bn[j][3], 0.f)) << 16);
+                } else {
+                    o.x = o.y = 0xFF80FF80u;
+                }
+                *reinterpret_cast<uint2*>(cv + i * CV_PX + j * 32 + kq * 8) = o;
+            }
+        }
+        __syncthreads();
+
+        // ---- 3x3/2 max over the tile.  Wave w owns pooled row w of the tile, lane (kq, m) pixel m and, for h = 0 / 1, the 8 channels
+        // 32 h + 8 kq .. + 8: a B-operand fragment of the branch2a product as it stands.
+        const int py = py0 + wave, px = px0 + m;
+        const bool live = py < p.H2 && px < p.W2;
+        uint4 pooled[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cg = 4 * h + kq;
+            float mx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int i = (2 * wave + dy) * CT_W + 2 * m + dx;
+                    const uint4 q = *reinterpret_cast<const uint4*>(cv + i * CV_PX + cg * 16);
+                    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        mx[2 * e] = fmaxf(mx[2 * e], __uint_as_float(w4[e] << 16));
+                        mx[2 * e + 1] = fmaxf(mx[2 * e + 1], __uint_as_float(w4[e] & 0xffff0000u));
+                    }
+                }
+            uint4 o;
+            o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+            o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+            o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+            o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
+            if (!live) o = make_uint4(0u, 0u, 0u, 0u);                     // a pixel past the image: finite operand, never stored
+            pooled[h] = o;
+            if (live) *reinterpret_cast<uint4*>(p.out + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + cg * 8)) = o;
+        }
+        if (A2) {       // a[px][perm rows] = relu(W2a . pooled[px] + b2a): D^T = W2a (A operand) x pooled^T (B operand)
+            f32x4 a2[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                a2[f] = (f32x4){ba[f][0], ba[f][1], ba[f][2], ba[f][3]};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {       // A fragment f, k half h of lane (kq, m): row 16 f + m, input channels 32 h + 8 kq .. + 8
+                    const uint4 wf = *reinterpret_cast<const uint4*>(w2l + (16 * f + m) * W2A_ROW + 64 * h + 16 * kq);
+                    a2[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, pooled[h]),
+                                                                    a2[f], 0, 0, 0);
                 }
             }
-        uint4 o;
-        o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
-        o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
-        o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
-        o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
-        *reinterpret_cast<uint4*>(out + ((((long long)b * H2 + py) * W2 + px) * 64 + cg * 8)) = o;
+            // lane (q = kq, column m): fragments 2 s and 2 s + 1 = channels 32 s + 8 q .. + 8 of pixel m
+#pragma unroll
+            for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                const f32x4 lo = a2[2 * sgrp], hi = a2[2 * sgrp + 1];
+                uint4 o;
+                o.x = (unsigned)to_bf16(fmaxf(lo[0], 0.f)) | ((unsigned)to_bf16(fmaxf(lo[1], 0.f)) << 16);
+                o.y = (unsigned)to_bf16(fmaxf(lo[2], 0.f)) | ((unsigned)to_bf16(fmaxf(lo[3], 0.f)) << 16);
+                o.z = (unsigned)to_bf16(fmaxf(hi[0], 0.f)) | ((unsigned)to_bf16(fmaxf(hi[1], 0.f)) << 16);
+                o.w = (unsigned)to_bf16(fmaxf(hi[2], 0.f)) | ((unsigned)to_bf16(fmaxf(hi[3], 0.f)) << 16);
+                if (live) *reinterpret_cast<uint4*>(p.a_out + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + 32 * sgrp + 8 * kq)) = o;
+            }
+        }
+        __syncthreads();                                  // the conv tile is dead: the next patch may be written
     }
 }
 
 }  // namespace
 
-extern "C" int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
-                                  const float* bias, void* out, int B, int H, int W) {
+static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows, const float* bias, void* out,
+                       int B, int H, int W, const void* w2a, const float* b2a, void* a_out) {
     if (!h) return RTN_EINVAL;
+    rtn_env_sync();
     if (!packed || !w_packed || !out) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: null pointer");
     if (B < 1 || H < 1 || W < 1 || B > 65535) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: bad extent");
     if (w_rows < 64) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: needs the 64 packed stem filters");
     if (((uintptr_t)packed & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)out & 15) || ((uintptr_t)bias & 3) || (Wp & 1))
         return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: misaligned pointer or odd Wp");
+    const bool a2 = a_out != nullptr;
+    if (a2 && (!w2a || !b2a || ((uintptr_t)w2a & 15) || ((uintptr_t)a_out & 15) || ((uintptr_t)b2a & 3) || a_out == out))
+        return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: a_out needs aligned branch2a filters / shifts and its own buffer");
     const int H1 = (H - 1) / 2 + 1, W1 = (W - 1) / 2 + 1;              // ZeroPadding2D(3) + 7x7/2 'valid'
     if (Hp < 2 * (H1 - 1) + 7 || Wp < 2 * (W1 - 1) + 8) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: packed image %dx%d too small for %dx%d", Hp, Wp, H, W);
     const long long bytes = (long long)B * Hp * Wp * 8;
     if (bytes >= 0xFFFFFF00ll) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: packed batch exceeds the 4 GiB buffer-descriptor range");
     const int H2 = (H1 + 1) / 2, W2 = (W1 + 1) / 2;                    // 3x3/2 'same'
     const int pth = (H2 - 1) * 2 + 3 - H1, ptw = (W2 - 1) * 2 + 3 - W1;
-    const int pool_pt = (pth > 0 ? pth : 0) / 2, pool_pl = (ptw > 0 ? ptw : 0) / 2;
-    dim3 grid((W2 + PT_W - 1) / PT_W, (H2 + PT_H - 1) / PT_H, B), block(256);
-    if (grid.y > 65535) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: image too tall");
-    hipLaunchKernelGGL(stem_fused_kernel, grid, block, 0, h->stream, (const char*)packed, (unsigned)bytes, (const char*)w_packed, bias,
-                       (unsigned short*)out, Hp, Wp, H1, W1, H2, W2, pool_pt, pool_pl);
+    StemParams p;
+    memset(&p, 0, sizeof(p));
+    p.xp = (const char*)packed; p.wk = (const char*)w_packed; p.bias = bias; p.out = (unsigned short*)out;
+    p.w2a = (const char*)w2a; p.b2a = b2a; p.a_out = (unsigned short*)a_out;
+    p.xp_bytes = (unsigned)bytes;
+    p.Hp = Hp; p.Wp = Wp; p.H1 = H1; p.W1 = W1; p.H2 = H2; p.W2 = W2;
+    p.pool_pt = (pth > 0 ? pth : 0) / 2; p.pool_pl = (ptw > 0 ? ptw : 0) / 2;
+    p.tiles_x = (W2 + PT_W - 1) / PT_W; p.tiles_y = (H2 + PT_H - 1) / PT_H;
+    const long long ntiles = (long long)p.tiles_x * p.tiles_y * B;
+    if (ntiles > 0x3fffffff) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: too many tiles");
+    p.ntiles = (int)ntiles;
+    long long grid = 2ll * (h->num_cus > 0 ? h->num_cus : 256);        // two workgroups per CU (LDS_BYTES each)
+    { const int gl = rtn_env_int("RTN_STEM_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: many tiles per workgroup on small images
+    if (grid > ntiles) grid = ntiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_A2));
+        attr_set = true;
+    }
+    if (a2) hipLaunchKernelGGL(stem_fused_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_BYTES_A2, h->stream, p);
+    else    hipLaunchKernelGGL(stem_fused_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_BYTES, h->stream, p);
     RTN_CHECK_LAUNCH(h, "stem_fused_kernel");
     return RTN_OK;
+}
+
+extern "C" int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
+                                  const float* bias, void* out, int B, int H, int W) {
+    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, nullptr, nullptr, nullptr);
+}
+
+extern "C" int rtn_stem_conv_pool_branch2a(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
+                                           const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out) {
+    if (h && !a_out) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool_branch2a: null a_out");
+    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, w2a, b2a, a_out);
 }

@@ -85,6 +85,7 @@ class Engine:
         self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
         self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
         self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
+        self.fuse_stem_2a = os.environ.get("RTN_FUSE_STEM_2A", "1") != "0"  # ... which also applies res2a_branch2a to the pooled pixels
         self.fuse_shortcut = os.environ.get("RTN_FUSE_SHORTCUT", "1") != "0"  # inference: branch1 folded into branch2c (dual-source GEMM)
         # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
         # + shortcut -> the next block's branch2a)
@@ -435,7 +436,8 @@ class Engine:
                                       flags=L.CONV_RELU | L.CONV_RES_SAME))
                 if block == 0:
                     first_blocks.append({"key": "res%s%s" % (s, bname), "i_b1": i_b1, "i_2c": len(ops) - 1, "x": x, "b2": b2, "y": y,
-                                         "Ho": Ho, "Wo": Wo, "step": st, "f": f, "a": a, "n2b": n2b,
+                                         "Ho": Ho, "Wo": Wo, "step": st, "f": f, "a": a, "n2b": n2b, "n2a": n2a,
+                                         "i_2a": None if (fp8_on and ("a", n2a) in self.fp8_scales) else i_2a,
                                          "i_2b": None if (fp8_on and ("a", n2a) in self.fp8_scales) else i_2b_cur})
                 if blocks64 and blocks64[-1].get("y") is None and blocks64[-1]["n2c"] == "res%s%s_branch2c" % (s, bname):
                     blocks64[-1].update({"i_2c": len(ops) - 1, "y": y})
@@ -518,7 +520,7 @@ class Engine:
         sched = self._schedule(ops)
         variants = {}
         bneck_ok = self.dtype == "bf16" and not fp8_on
-        for fs in (False, True):                         # fuse_stem
+        for fs in (0, 1, 2):                             # fuse_stem: 1 = conv1 + ReLU + pool1, 2 = ... + res2a_branch2a
             for fd in (False, True):                     # fuse_shortcut
                 for fk in ((0, 1, 2) if bneck_ok else (0,)):      # fuse_bottleneck: 1 = inference, 2 = training (branch2b's output is kept)
                     if not fs and not fd and not fk:
@@ -541,7 +543,13 @@ class Engine:
                             if nxt is not None:
                                 v[nxt["i_2a"]] = None
                     if fs:
-                        v = [v[0], stem_fused] + v[n_stem_ops:]          # pack, then conv1 + ReLU + pool1 as one launch
+                        sf = stem_fused
+                        fb0 = first_blocks[0]
+                        if fs == 2 and fb0["f"] == 64 and fb0["step"] == 1 and fb0["i_2a"] is not None and v[fb0["i_2a"]] is not None:
+                            w2a, b2a = self.w[fb0["n2a"]][:2]             # the pooled pixels go through res2a_branch2a before they leave the registers
+                            sf = stem_fused + ((fb0["a"], w2a, b2a),)
+                            v[fb0["i_2a"]] = None
+                        v = [v[0], sf] + v[n_stem_ops:]                  # pack, then conv1 + ReLU + pool1 as one launch
                     v = [op for op in v if op is not None]
                     variants[(fs, fd, fk)] = (v, self._schedule(v))
         plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "a_acts": a_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
@@ -567,7 +575,7 @@ class Engine:
         if kind == "pack":
             return [], [op[1].data_ptr()]
         if kind == "stem":
-            return [op[5].data_ptr()], [op[1].data_ptr()]
+            return [op[5].data_ptr()], [op[1].data_ptr()] + ([op[7][0].data_ptr()] if len(op) > 7 else [])
         if kind == "dual":
             return [t.data_ptr() for t in op[4]["xs"]], [t.data_ptr() for t in op[4]["ys"]]
         if kind == "bneck":
@@ -687,7 +695,7 @@ class Engine:
         return plan["regression"], plan["classification"]
 
     def _fused(self):
-        """(stem fused, shortcut fused, 64-channel bottleneck blocks fused) or None.  Training keeps conv1 / pool1 separate (the
+        """(stem fused: 0 / 1 / 2 = with res2a_branch2a, shortcut fused, 64-channel bottleneck blocks fused) or None.  Training keeps conv1 / pool1 separate (the
         backward needs conv1's output and the pooling argmax) and every bottleneck tensor (the backward reads them); the folded
         shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and filters.  The fused stem and the fused
         bottleneck exist for bf16 only; the fp8 plan keeps its own branch2a / branch2b pairing."""
@@ -695,7 +703,8 @@ class Engine:
         fk = 0
         if self.fuse_bottleneck and self.dtype == "bf16" and not self._fp8_on():
             fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
-        key = (self.fuse_stem and infer16, self.fuse_shortcut, fk)
+        fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and infer16) else 0
+        key = (fs, self.fuse_shortcut, fk)
         return key if any(key) else None
 
     def active_ops(self, plan):
@@ -720,8 +729,14 @@ class Engine:
             h.check(lib.rtn_quantize_fp8(h.raw, op[1].data_ptr(), self.rdt, op[2].data_ptr(), op[1].numel(), op[3]))
         elif kind == "stem":
             Bn, Hn, Wn = op[2]
-            h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
-                                           op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn))
+            if len(op) > 7:                              # + res2a_branch2a on the pooled pixels
+                a_out, w2a, b2a = op[7]
+                h.check(lib.rtn_stem_conv_pool_branch2a(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
+                                                        op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn, w2a.data_ptr(), b2a.data_ptr(),
+                                                        a_out.data_ptr()))
+            else:
+                h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
+                                               op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn))
         elif kind == "pack":
             xi = op[2]
             h.check(lib.rtn_stem_pack(h.raw, images.data_ptr(), _SRC_DT[images.dtype], op[1].data_ptr(), self.rdt,

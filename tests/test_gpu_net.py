@@ -191,6 +191,49 @@ def test_fused_stem_matches_the_three_kernel_stem(pkg, state, hw, src):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hw,grid", [((64, 96), 0), ((131, 203), 3), ((97, 160), 1), ((33, 35), 0)])
+def test_stem_with_branch2a_matches_the_separate_layer(pkg, state, monkeypatch, hw, grid):
+    """rtn_stem_conv_pool_branch2a: the persistent stem kernel also applies res2a_branch2a (1x1, 64 -> 64, BN, ReLU; keras_resnet
+    bottleneck behind model/defineModel.py:376-380) to the pooled pixels.  pool1 must equal the stem-only kernel's BIT FOR BIT (same
+    MFMA order); the branch2a tensor is compared with the separate rtn_conv2d_fwd launch on that pool1: same bf16 operands, another
+    f32 summation order (bias first), so one bf16 ulp of the activation scale (stated: 2^-7 of the largest activation, most elements
+    identical).  RTN_STEM_GRID limits the workgroups: up to 60 tiles per workgroup through the register prefetch of the next patch."""
+    E, _ = mods(pkg)
+    B = 2
+    if grid:
+        monkeypatch.setenv("RTN_STEM_GRID", str(grid))
+    g = torch.Generator().manual_seed(hw[0])
+    x = (torch.rand(B, hw[0], hw[1], 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.load_state(state)
+    plan = eng._plan(B, hw[0], hw[1])
+    pool_out = [op for op in plan["ops"] if op[0] == "pool"][0][2]
+    a_out = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "res2a_branch2a"][0][3]["ys"][0]
+    outs = {}
+    for with2a in (False, True):
+        eng.fuse_stem_2a = with2a
+        pool_out.fill_(-3.0)
+        a_out.fill_(-3.0)
+        reg, cls = eng.forward(x)
+        torch.cuda.synchronize()
+        names = [op[2] for op in eng.active_ops(plan) if op[0] == "conv"]
+        stem = [op for op in eng.active_ops(plan) if op[0] == "stem"][0]
+        assert ("res2a_branch2a" in names) == (not with2a) and (len(stem) > 7) == with2a
+        outs[with2a] = (pool_out.clone(), a_out.float().cpu().clone(), reg.clone(), cls.clone())
+    assert torch.equal(outs[False][0], outs[True][0])
+    a, b = outs[False][1], outs[True][1]
+    scale = float(a.abs().max())
+    err, same = float((a - b).abs().max()), float((a == b).float().mean())
+    print("branch2a in the stem: max |diff| %.3e (scale %.2f), identical elements %.4f" % (err, scale, same))
+    assert scale > 0.1 and err <= scale * 2.0 ** -7 and same > 0.9
+    assert torch.isfinite(outs[True][2]).all() and torch.isfinite(outs[True][3]).all()
+    # a second run repeats bit for bit (tile order and prefetch do not matter)
+    eng.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a_out.float().cpu(), b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,hw", [("bf16", (160, 224)), ("f32", (96, 128))])
 def test_fused_shortcut_matches_separate_layers(pkg, state, dtype, hw):
     """rtn_conv1x1_dual_fwd folds the projection shortcut of every stage's first block into its branch2c as extra K
