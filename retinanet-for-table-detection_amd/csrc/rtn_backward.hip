@@ -528,6 +528,200 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const
         }
 }
 
+// ------------------------------------------------------------------------------------------------ 256 x 256, LDS-DMA RING (bf16)
+// conv_wgrad_dma_kernel<4, 2, 8> stages one 64-pixel step ahead and ends every step with vmcnt(0) + barrier: the whole LDS-DMA
+// latency of 64 KB per CU (all 256 CUs bursting together) stands between two steps, and the loop runs at 3.0 us per 64 pixels for
+// 0.86 us of MFMA work (head-tower layer: 0.29 ms, 0.29 of peak, twice the forward kernel).  Same tile, same LDS image, same
+// fragment reads here, but the pixel stream is cut into 32-pixel stages (one 16x16x32 MFMA slab) in a RING OF FOUR: the stage
+// multiplied in iteration i was requested in iteration i - 3, the one counted wait per iteration (vmcnt(8): everything but the two
+// youngest stages) never waits for a request younger than two iterations.  vmcnt retires in order, so the per-pixel row info (16 B:
+// tap-(0,0) offset, dY offset, iy0 | ix0) may not come through vector loads (a wait for it would drain the DMAs issued before it):
+// the four rows a wave stages per piece pair are wave-uniform and adjacent, and come in through two s_load_dwordx8 (lgkmcnt).
+// Past the end of the split the DMAs are still issued, out of range (zeros into a ring slot nobody reads), so the count is fixed.
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+
+__device__ __forceinline__ u32x8 wr_sload8(const void* base, unsigned byte_off) {
+    u32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const WParams p) {
+    constexpr int NW = 8, NWK = 2, FJ = 8, TS = 256;
+    constexpr int WD_ROWB = TS * 2;               // 512 bytes per pixel row of an operand tile
+    constexpr int PX = 32;                        // pixels per stage
+    constexpr int OP_B = PX * WD_ROWB;            // 16 KB per operand and stage
+    constexpr int NST = 4;
+    constexpr int CPR = WD_ROWB / 16;             // 32 chunks per row
+    __shared__ __attribute__((aligned(16))) char lds[NST * 2 * OP_B];   // [stage][dY | X] = 128 KB
+
+    int otile, split;
+    if (p.xcd_map) {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int sl = j / p.out_tiles;
+        otile = j - sl * p.out_tiles;
+        split = sl * 8 + xcd;
+    } else {
+        otile = blockIdx.x;
+        split = blockIdx.y;
+    }
+    const int tile_n = otile / p.ntiles_k;
+    const int tile_k = otile - tile_n * p.ntiles_k;
+    const int n0 = tile_n * TS, k0 = tile_k * TS;
+    const int tlo = split * p.tiles_per_split;
+    int thi = tlo + p.tiles_per_split;
+    thi = thi < p.total_tiles ? thi : p.total_tiles;
+    if (tlo >= thi) return;
+    const int hlo = 2 * tlo, hhi = 2 * thi;       // 32-pixel half tiles
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // ---- staging role: piece i (0, 1) of this wave = rows 2 wave + 16 i + (lane >> 5), LDS chunk position lane & 31
+    const int rsub = lane >> 5;
+    const int srow0 = 2 * wave + rsub;
+    const int skey = (srow0 & 3) | (((srow0 >> 3) & 1) << 2);  // the same for both pieces (+16 keeps row & 3 and bit 3)
+    const int sc = (lane & (CPR - 1)) ^ (skey << 1);           // source chunk (8 elements) this lane fetches
+    const int kk = k0 + sc * 8;
+    const bool kvalid = kk < p.Ktot;
+    const int kpos = kk >> p.cshift;
+    const int coff = kk & p.crun_mask;
+    const int kh = (kpos * p.kw_inv) >> 16;
+    const int kw = kpos - kh * p.KW;
+    const int nn = n0 + sc * 8;
+    const bool nvalid = nn < p.N;
+    const unsigned dyo = (unsigned)(nn * 2);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    const int wm = wave / NWK, wn = wave % NWK;
+    f32x4 acc[4][FJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = p.db != nullptr && tile_k == 0 && wn == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // row info of half tile H, piece i: rows H * 32 + 2 wave + 16 i and the next one (32 bytes, wave-uniform)
+    auto ri_load = [&](int H, int i) -> u32x8 {
+        const int Hc = H < hhi ? H : hhi - 1;
+        return wr_sload8(p.rowinfo, (unsigned)((Hc * 32 + 2 * wave + 16 * i) * 16));
+    };
+    auto stage = [&](int H, int slot, const u32x8& r0, const u32x8& r1) {
+        const bool live = H < hhi;
+        int gi_ = 0;
+#pragma unroll
+        for (int i_ = 1; i_ < RTN_MAX_GROUPS; ++i_)
+            if (i_ < p.ngroups && (H >> 1) >= p.g[i_].tile_begin) gi_ = i_;
+        const WGroup& G_ = p.g[live ? gi_ : 0];
+        const i32x4 xs_ = wd_make_srd(G_.x, G_.x_bytes);
+        const i32x4 ys_ = wd_make_srd(G_.dy, G_.dy_bytes);
+        const unsigned delta_ = (unsigned)(kh * G_.x_row_stride_b + kw * p.pix_stride_b + coff * 2);
+        const int Hin_ = G_.Hin, Win_ = G_.Win;
+#pragma unroll
+        for (int i_ = 0; i_ < 2; ++i_) {
+            const u32x8& r = i_ ? r1 : r0;
+            const unsigned rx = rsub ? r[4] : r[0], ry = rsub ? r[5] : r[1], rz = rsub ? r[6] : r[2];
+            const int iy_ = (int)(short)(rz & 0xffffu) + kh, ix_ = (int)(short)(rz >> 16) + kw;
+            const bool ok_ = live && kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;
+            const unsigned piece_ = (unsigned)((wave + NW * i_) * 1024);
+            wd_dma16(ys_, (live && nvalid && ry != OOB_OFFSET) ? ry + dyo : OOB_OFFSET, lds_base + (unsigned)(slot * 2 * OP_B) + piece_);
+            wd_dma16(xs_, ok_ ? rx + delta_ : OOB_OFFSET, lds_base + (unsigned)(slot * 2 * OP_B + OP_B) + piece_);
+        }
+    };
+#define WR_RI_WAIT(A, B) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) :: "memory")
+
+    // ---- prologue: stages 0..2 requested, the row info of stage 3 on its way
+    u32x8 ra = ri_load(hlo, 0), rb = ri_load(hlo, 1);
+    WR_RI_WAIT(ra, rb);
+    stage(hlo, 0, ra, rb);
+    ra = ri_load(hlo + 1, 0); rb = ri_load(hlo + 1, 1);
+    WR_RI_WAIT(ra, rb);
+    stage(hlo + 1, 1, ra, rb);
+    ra = ri_load(hlo + 2, 0); rb = ri_load(hlo + 2, 1);
+    WR_RI_WAIT(ra, rb);
+    stage(hlo + 2, 2, ra, rb);
+    ra = ri_load(hlo + 3, 0); rb = ri_load(hlo + 3, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // stage 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rkey = q | ((g & 1) << 2);
+    const int row = 8 * g + q;
+#pragma unroll 1
+    for (int H = hlo; H < hhi; ++H) {
+        const int cur = (H - hlo) & 3;
+        const char* A = lds + cur * 2 * OP_B;          // dY stage
+        const char* B = A + OP_B;                      // X stage
+        // the row info requested one iteration ago is here: request stage H + 3 into the slot stage H - 1 was read from
+        WR_RI_WAIT(ra, rb);
+        stage(H + 3, (cur + 3) & 3, ra, rb);
+        ra = ri_load(H + 4, 0); rb = ri_load(H + 4, 1);
+        s16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;            // byte column inside the 512-byte row
+            const int aoff = row * WD_ROWB + (((ca >> 5) ^ rkey) << 5) + (ca & 31);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WD_ROWB));
+            af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        if (do_bias) {                              // BiasAddGrad: the A fragment of lane (m, kq) holds 8 pixels of channel m
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((unsigned)(unsigned short)af[i][e]) << 16);
+        }
+#pragma unroll
+        for (int jh = 0; jh < FJ; jh += 4) {
+            s16x8 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cb = (wn * 16 * FJ + 16 * (jh + j) + 4 * pp) * 2;
+                const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
+                const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
+                const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
+                bf[j] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                             __builtin_bit_cast(bf16x8, bf[j]), acc[i][jh + j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage H + 1 has landed; H + 2 and H + 3 stay in flight
+        __builtin_amdgcn_s_barrier();
+    }
+#undef WR_RI_WAIT
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may land in LDS (or in SGPRs) after the loop
+
+    const int lr = (lane >> 4) * 4, lc = lane & 15;
+    if (do_bias) {       // lane (m = lane & 15, kq = lane >> 4): fold the four pixel groups, lanes 0..15 add channel m
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wm * 64 + 16 * i + lc;
+            if (lane < 16 && n < p.db_n) { if (p.slab) p.bslab[(long long)split * p.N + n] = v; else unsafeAtomicAdd(p.db + n, v); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int kc = k0 + wn * 16 * FJ + 16 * j + lc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 64 + 16 * i + lr + r;
+                if (n < p.N && kc < p.Ktot) {
+                    if (p.slab) p.slab[((long long)split * p.N + n) * p.Ktot + kc] = acc[i][j][r];
+                    else unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
+                }
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 template <int ES>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const char* __restrict__ dy, long long rows, int N, long long ld_b,
@@ -1241,7 +1435,10 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.out_tiles = (int)out_tiles;
     p.xcd_map = xcd_map ? 1 : 0;
     dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
-    if (dma)            hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
+    // the ring kernel reads the row-info table through 32-bit scalar offsets: tables beyond 4 GiB stay on the two-stage kernel
+    const bool ring = dma && rtn_env_int("RTN_WGRAD_RING", 1) != 0 && (long long)tiles * 64 * 16 < (1ll << 32);
+    if (ring)           hipLaunchKernelGGL(conv_wgrad_ring_kernel, grid, dim3(512), 0, h->stream, p);
+    else if (dma)       hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
     else if (dma_small) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2, 4>), grid, dim3(256), 0, h->stream, p);
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);

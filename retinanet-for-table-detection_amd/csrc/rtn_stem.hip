@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
     // their halo columns / rows through ONE L2)
     int tile, tile_end, tstep;
     {
-        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x, xcd = bid & 7, idx = bid >> 3;
-        const int wgs = nwg / 8 + (xcd < (nwg & 7) ? 1 : 0);
-        const int lo = (int)((long long)p.ntiles * xcd / 8), hi = (int)((long long)p.ntiles * (xcd + 1) / 8);
-        tile = lo + idx; tile_end = hi; tstep = wgs > 0 ? wgs : 1;
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+        const int nx = nwg < 8 ? nwg : 8;                  // fewer than 8 workgroups: as many ranges as workgroups
+        const int xcd = bid % nx, idx = bid / nx;
+        const int wgs = nwg / nx + (xcd < nwg % nx ? 1 : 0);
+        const int lo = (int)((long long)p.ntiles * xcd / nx), hi = (int)((long long)p.ntiles * (xcd + 1) / nx);
+        tile = lo + idx; tile_end = hi; tstep = wgs;
     }
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.xp), (short)0, (int)p.xp_bytes, 0x00020000);
     u32x4 pf[NPF];

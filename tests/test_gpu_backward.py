@@ -573,3 +573,55 @@ def test_pack_dgrad_multi_equals_per_layer_pack(pkg, handle):
     torch.cuda.synchronize()
     for wd, ref in want:
         assert torch.equal(wd, ref)
+
+
+def test_wgrad_ring_kernel_equals_the_two_stage_kernel_bit_for_bit(pkg, handle, monkeypatch):
+    """conv_wgrad_ring_kernel (256 x 256 tile, 32-pixel stages in a ring of four, row info through scalar loads, counted vmcnt) adds
+    the same bf16 products in the same order as conv_wgrad_dma_kernel<4, 2, 8> (64-pixel steps, two stages): a head-tower-like layer
+    over five levels with the bias gradient fused, pixel counts that end in the middle of a 64-pixel tile, and a split boundary
+    inside a level - dW and db must be identical bits (RTN_WGRAD_RING=0 selects the two-stage kernel)."""
+    L = pkg._lib
+    tdt, code = DT["bf16"]
+    B, cin, cout = 2, 256, 512
+    levels = [(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)]
+    g = torch.Generator().manual_seed(23)
+    total = sum(h * w for h, w in levels)
+    dy = torch.randn(B, total, cout, generator=g).to(tdt).to(DEV).contiguous()
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = 1
+    d.out_ld = cout
+    keep, off = [], 0
+    for gi, (H, W) in enumerate(levels):
+        xd = torch.randn(B, H, W, cin, generator=g).to(tdt).to(DEV).contiguous()
+        keep.append(xd)
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems = dy.data_ptr(), dy.numel()
+        grp.out_img_stride, grp.out_off = total * cout, off * cout
+        d.g[gi] = grp
+        off += H * W
+    monkeypatch.setenv("RTN_WGRAD_DMA", "2")
+    got = {}
+    for ring in ("0", "1", "1"):
+        monkeypatch.setenv("RTN_WGRAD_RING", ring)
+        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dW = torch.zeros(cout, 9 * cin, dtype=torch.float32, device=DEV)
+        db = torch.zeros(cout, dtype=torch.float32, device=DEV)
+        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        torch.cuda.synchronize()
+        assert L.lib.rtn_debug_last_wgrad_impl(handle.raw) == 2
+        got.setdefault(ring, []).append((dW.cpu(), db.cpu()))
+    (w0, b0), (w1, b1), (w2, b2) = got["0"][0], got["1"][0], got["1"][1]
+    assert float(w0.abs().max()) > 1.0
+    assert torch.equal(w1, w2) and torch.equal(b1, b2)
+    assert torch.equal(w0, w1), "ring kernel differs from the two-stage kernel: max %.3e" % float((w0 - w1).abs().max())
+    assert torch.equal(b0, b1)
+    want_db = dy.float().cpu().double().sum(dim=(0, 1))
+    assert float((b1.double() - want_db).abs().max()) <= 1e-4 * float(want_db.abs().max())

@@ -39,13 +39,20 @@ print("forward      %.3f ms" % timed(lambda: eng.forward(x)))
 bp = tr._bplan(B, *bench.CANVAS)
 acc = collections.OrderedDict()
 tr.grad.zero_()
+tabs = {}
+for b in bp["bops"]:
+    if b[0] == "wgrad":
+        tab = torch.empty(L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(b[1])), dtype=torch.uint8, device="cuda")
+        eng.h.check(L.lib.rtn_conv2d_wgrad_rowinfo(eng.h.raw, C.byref(b[1]), tab.data_ptr(), tab.numel()))
+        tabs[id(b)] = tab
+torch.cuda.synchronize()
 for b in bp["bops"]:
     kind = b[0]
     h, lib = eng.h, L.lib
     def run():
-        if kind == "wgrad":
-            if b[4] is not None: h.check(lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr(), b[5], bp["ws"].data_ptr(), bp["ws"].numel()))
-            else: h.check(lib.rtn_conv2d_wgrad(h.raw, C.byref(b[1]), b[2].data_ptr(), bp["ws"].data_ptr(), bp["ws"].numel()))
+        if kind == "wgrad":          # as the trainer runs it: on the row-info table built once per layer
+            h.check(lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr() if b[4] is not None else None,
+                                                  b[5] if b[4] is not None else 0, tabs[id(b)].data_ptr(), tabs[id(b)].numel()))
         elif kind == "dgrad": h.check(lib.rtn_conv2d_dgrad(h.raw, C.byref(b[1])))
         elif kind == "bgrad": h.check(lib.rtn_bias_grad(h.raw, b[1].data_ptr(), eng.rdt, b[2], b[3], b[4], b[5].data_ptr()))
         elif kind == "padcast": h.check(lib.rtn_pad_cast_rows(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, b[3], b[4], b[5]))
