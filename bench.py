@@ -110,6 +110,22 @@ def pmc_traffic(n_conv_launches):
     return float(tot["hbm_bytes_per_step"]), tag
 
 
+def pmc_traffic_train():
+    """HBM bytes per TRAINING step (batch 16) from the newest committed profiles/*pmc_train_traffic*.json (tools/pmc_train.py: two
+    rocprofv3 --pmc passes over `bench.py --mode train`, FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of a step)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_train_traffic*.json")))
+    if not files:
+        return None, "no PMC summary of the training step committed"
+    try:
+        with open(files[-1]) as f:
+            j = json.load(f)
+        return float(j["hbm_bytes_per_step"]), "profiles/%s (commit %s, %s steps of batch %s, 2 x FETCH_SIZE + WRITE_SIZE over all kernels)" % (
+            os.path.basename(files[-1]), j.get("git_commit", "unrecorded"), j.get("steps"), j.get("batch"))
+    except (OSError, KeyError, ValueError) as e:
+        return None, "unreadable PMC summary %s: %s" % (os.path.basename(files[-1]), e)
+
+
 def cpu_baseline(torch, state, threads):
     import numpy as np
     from oracle import ref_numpy as R
@@ -195,6 +211,37 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
     value = world * B * steps / elapsed
     s = tr.norm_sums.cpu().numpy()
     achieved = value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world
+    # dominant kernel of the training step: the head-tower weight gradients (8 launches of the 256 x 256 LDS-DMA kernel, the largest
+    # single share of the backward pass).  Measured live after the timed region: events on the launch stream around each launch,
+    # launches one after another (untimed extra launches into the same gradient buffer, which the next step would zero anyway).
+    dom = None
+    try:
+        bp = tr._bplan(B, CANVAS[0], CANVAS[1])
+        tower = [(bi, b) for bi, b in enumerate(bp["bops"]) if b[0] == "wgrad" and str(b[3]).startswith(("pyramid_regression_", "pyramid_classification_"))
+                 and bi in bp["rowinfo"]]
+        if tower:
+            eng._bind_stream()
+            times = []
+            for bi, b in tower:
+                tab = bp["rowinfo"][bi]
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(3):
+                    eng.h.check(L.lib.rtn_conv2d_wgrad_prepared(eng.h.raw, C.byref(b[1]), b[2].data_ptr(), b[4].data_ptr() if b[4] is not None else None,
+                                                                b[5] if b[4] is not None else 0, tab.data_ptr(), tab.numel()))
+                ev[1].record()
+                torch.cuda.synchronize()
+                times.append(ev[0].elapsed_time(ev[1]) / 3)
+            d0 = tower[0][1][1]
+            fl = 2.0 * sum(d0.g[i].Hout * d0.g[i].Wout for i in range(d0.ngroups)) * B * d0.N * d0.KH * d0.KW * d0.Crun
+            t_ms = sum(times) / len(times)
+            dom = {"kernel": "conv_wgrad_dma_kernel<4, 2, 8> + wgrad_finish_kernel (head-tower weight gradients: 3x3 256->256 over P3..P7, one grouped launch each)",
+                   "launches_per_step": len(tower), "flop_per_launch": fl, "avg_launch_ms_solo": t_ms, "achieved_solo": fl / (t_ms * 1e-3) / 1e12,
+                   "frac_solo": fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "impl": int(L.lib.rtn_debug_last_wgrad_impl(eng.h.raw)),
+                   "how": "events on the launch stream around 3 launches of each layer after the timed region (row-info table prebuilt, ordered slab reduction included)"}
+    except Exception as e:              # the measurement beside the line may fail; the line itself may not
+        dom = {"error": "%s: %s" % (type(e).__name__, e)}
+    traffic, traffic_note = pmc_traffic_train()
     return {"metric": "images/sec RetinaNet R50-FPN 800x1333 training step", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -204,7 +251,8 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
                        "parallelism": "dp%d (bucketed gradient all-reduce overlapped with backward)" % world},
             "roofline": {"bound": "mfma", "kernel": "conv fwd+dgrad+wgrad (whole step)", "achieved": achieved,
                          "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
-                         "flop_per_step": TRAIN_GFLOP_PER_IMAGE * 1e9 * B, "traffic": None}}
+                         "flop_per_step": TRAIN_GFLOP_PER_IMAGE * 1e9 * B, "traffic": traffic, "traffic_per": "step",
+                         "traffic_source": traffic_note, "dominant": dom}}
 
 
 def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):

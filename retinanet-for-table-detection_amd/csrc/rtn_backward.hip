@@ -546,6 +546,7 @@ __device__ __forceinline__ u32x8 wr_sload8(const void* base, unsigned byte_off) 
     return v;
 }
 
+template <bool STAGGER>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const WParams p) {
     constexpr int NW = 8, NWK = 2, FJ = 8, TS = 256;
     constexpr int WD_ROWB = TS * 2;               // 512 bytes per pixel row of an operand tile
@@ -647,16 +648,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const WParams p
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int rkey = q | ((g & 1) << 2);
     const int row = 8 * g + q;
+    // Two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run ONE BARRIER APART, as in rtn_conv_halo8.hip: an iteration is
+    // {R: request stage H + 3, read all fragments of stage H | barrier | M: 32 MFMAs | barrier}, so while one wave of a SIMD
+    // multiplies the other issues its LDS-DMA pieces and fragment reads.  The counted wait sits at the END of R: a wave's pieces of
+    // stage H + 1 have landed one barrier before the other group's (two before its own) reads of that stage; all fragment reads have
+    // returned before the barrier that ends R, two intervals before any wave requests the stage that overwrites their slot.
+    const int grp = wave >> 2;
+    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int H = hlo; H < hhi; ++H) {
         const int cur = (H - hlo) & 3;
         const char* A = lds + cur * 2 * OP_B;          // dY stage
         const char* B = A + OP_B;                      // X stage
-        // the row info requested one iteration ago is here: request stage H + 3 into the slot stage H - 1 was read from
+        // ---- R: the row info requested one iteration ago is here: request stage H + 3 into the slot stage H - 1 was read from
         WR_RI_WAIT(ra, rb);
         stage(H + 3, (cur + 3) & 3, ra, rb);
         ra = ri_load(H + 4, 0); rb = ri_load(H + 4, 1);
-        s16x8 af[4];
+        s16x8 af[4], bf[FJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;            // byte column inside the 512-byte row
@@ -665,33 +673,39 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const WParams p
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WD_ROWB));
             af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int cb = (wn * 16 * FJ + 16 * j + 4 * pp) * 2;
+            const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
+            const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
+            const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
+            bf[j] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+        }
+        // stage H + 1 has landed (H + 2, H + 3 stay in flight); every fragment read above has returned (the scalar row-info loads too)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+s"(ra), "+s"(rb) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                    __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         if (do_bias) {                              // BiasAddGrad: the A fragment of lane (m, kq) holds 8 pixels of channel m
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((unsigned)(unsigned short)af[i][e]) << 16);
         }
-#pragma unroll
-        for (int jh = 0; jh < FJ; jh += 4) {
-            s16x8 bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cb = (wn * 16 * FJ + 16 * (jh + j) + 4 * pp) * 2;
-                const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
-                const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
-                const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
-                bf[j] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                             __builtin_bit_cast(bf16x8, bf[j]), acc[i][jh + j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage H + 1 has landed; H + 2 and H + 3 stay in flight
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();
 #undef WR_RI_WAIT
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may land in LDS (or in SGPRs) after the loop
 
@@ -1258,7 +1272,10 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     // (A 256 x 256-tile, 512-thread variant of the kernel was built and measured: no faster at equal rounds - the loop is
     // bound by the latency of its register-staged loads, not by MFMA work per byte.)
     const long long slots = (long long)(cus > 0 ? cus : 256) * (w.dma ? 1 : 2);
-    long long target = slots * (w.dma_small ? 1 : 2);      // measured (RTN_WGRAD_BLOCKS sweep): one round for the 128 x 128 DMA kernel
+    // measured (RTN_WGRAD_BLOCKS sweep): one round for both LDS-DMA kernels.  Round 3, 256 x 256 kernel with the slab reduction
+    // (profiles/r3_wgrad_blocks_ab.txt): 256 workgroups 0.268 ms against 0.282 with 512 on a head-tower layer, 0.209 / 0.223 on P3 -
+    // every split writes a 2.4 MB slab that the finish kernel reads back (PMC: 132 MB written per layer with 56 splits)
+    long long target = slots * ((w.dma_small || w.dma) ? 1 : 2);
     { const long long v = rtn_env_int("RTN_WGRAD_BLOCKS", 0); if (v >= 64 && v <= 65536) target = v; }
     long long nsplit = target / w.out_tiles;
     if (nsplit > w.tiles) nsplit = w.tiles;
@@ -1436,8 +1453,9 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.xcd_map = xcd_map ? 1 : 0;
     dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
     // the ring kernel reads the row-info table through 32-bit scalar offsets: tables beyond 4 GiB stay on the two-stage kernel
-    const bool ring = dma && rtn_env_int("RTN_WGRAD_RING", 1) != 0 && (long long)tiles * 64 * 16 < (1ll << 32);
-    if (ring)           hipLaunchKernelGGL(conv_wgrad_ring_kernel, grid, dim3(512), 0, h->stream, p);
+    const bool ring = dma && rtn_env_int("RTN_WGRAD_RING", 0) != 0 && (long long)tiles * 64 * 16 < (1ll << 32);
+    if (ring && rtn_env_int("RTN_WGRAD_RING_STAGGER", 1) != 0) hipLaunchKernelGGL(conv_wgrad_ring_kernel<true>, grid, dim3(512), 0, h->stream, p);
+    else if (ring)      hipLaunchKernelGGL(conv_wgrad_ring_kernel<false>, grid, dim3(512), 0, h->stream, p);
     else if (dma)       hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
     else if (dma_small) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2, 4>), grid, dim3(256), 0, h->stream, p);
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);

@@ -27,18 +27,24 @@ __device__ __forceinline__ void dma16(const i32x4& srd, unsigned voff, unsigned 
                  : "=&s"(keep) : "v"(voff), "s"(la), "s"(srd) : "memory");
 }
 
-constexpr int WINDOW = 64 * 1024;      // per workgroup
+constexpr int WINDOW = 64 * 1024;      // LDS bytes per workgroup
+constexpr int SRCW = 512 * 1024;       // source bytes a workgroup sweeps (beyond the vector L1: served by the XCD's L2)
 constexpr int ITERS = 64;              // sweeps of the window
 
+// share: 0 = every workgroup sweeps its OWN window; 1 = ALL workgroups sweep the same window in the same piece order (what the weight
+// tiles of the convolution kernels do: 256 CUs request the same lines at the same time); 2 = the same window, but workgroup b starts
+// its sweep at piece (b * 7) mod pieces (the simultaneous requests of different CUs go to different lines / L2 channels)
 template <int MODE>                    // 0 = LDS-DMA, 1 = registers
-__global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned long long* clocks, int nissue, float* sink) {
+__global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned long long* clocks, int nissue, float* sink, int share) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    const char* win = src + (size_t)blockIdx.x * WINDOW;
-    const i32x4 srd = make_srd(win, WINDOW);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)win, 0, WINDOW, 0x00020000);
+    const char* win = src + ((share && share != 3) ? 0 : (size_t)blockIdx.x * SRCW);
+    const i32x4 srd_sh = make_srd(src, SRCW);           // share == 3: three pieces of four come from the window EVERY workgroup reads (L2 hits), one from its own (memory side)
+    const unsigned rot = share == 2 ? (blockIdx.x * 37u) % (SRCW / 1024u) : 0u;
+    const i32x4 srd = make_srd(win, SRCW);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)win, 0, SRCW, 0x00020000);
     __syncthreads();
     unsigned long long t0 = 0, t1 = 0;
     if (wave == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
@@ -50,7 +56,9 @@ __global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned lo
 #pragma unroll 8
                 for (int k = 0; k < per; ++k) {
                     const unsigned piece = (unsigned)(wave * per + k);
-                    dma16(srd, piece * 1024u + (unsigned)lane * 16u, lds_base + piece * 1024u);
+                    const unsigned spiece = (piece + (unsigned)(it % (SRCW / WINDOW)) * (WINDOW / 1024u) + rot) % (SRCW / 1024u);
+                    if (share == 3 && (k & 3) != 3) dma16(srd_sh, spiece * 1024u + (unsigned)lane * 16u, lds_base + piece * 1024u);
+                    else dma16(srd, spiece * 1024u + (unsigned)lane * 16u, lds_base + piece * 1024u);
                 }
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             } else {
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned lo
                     u32x4 v[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
-                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((unsigned)(wave * per + k0 + k)) * 1024u + (unsigned)lane * 16u), 0, 0);
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((unsigned)(wave * per + k0 + k) + (unsigned)(it % (SRCW / WINDOW)) * (WINDOW / 1024u)) % (SRCW / 1024u)) * 1024u + (unsigned)lane * 16u), 0, 0);
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
                         *reinterpret_cast<u32x4*>(lds + (wave * per + k0 + k) * 1024 + lane * 16) = v[k];
@@ -85,23 +93,24 @@ int main() {
     char* src;
     unsigned long long* clk;
     float* sink;
-    hipMalloc(&src, (size_t)cus * WINDOW);
-    hipMemset(src, 1, (size_t)cus * WINDOW);
+    hipMalloc(&src, (size_t)cus * SRCW);
+    hipMemset(src, 1, (size_t)cus * SRCW);
     hipMalloc(&clk, cus * sizeof(unsigned long long));
     hipMalloc(&sink, cus * sizeof(float));
     hipFuncSetAttribute((const void*)stage_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
     hipFuncSetAttribute((const void*)stage_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("%d CUs, %d KiB window per workgroup, %d sweeps (L2-resident after the first)\n", cus, WINDOW / 1024, ITERS);
-    for (int mode = 0; mode < 2; ++mode)
+    printf("%d CUs, %d KiB source window per workgroup staged through %d KiB of LDS, %d sweeps of 64 KiB\n", cus, SRCW / 1024, WINDOW / 1024, ITERS);
+    for (int share = 0; share < 4; ++share)
+    for (int mode = 0; mode < (share ? 1 : 2); ++mode)
         for (int nissue : {1, 2, 4, 8}) {
             float best_ms = 1e9f;
             std::vector<unsigned long long> h(cus);
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(stage_kernel<0>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
-                else           hipLaunchKernelGGL(stage_kernel<1>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
+                if (mode == 0) hipLaunchKernelGGL(stage_kernel<0>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink, share);
+                else           hipLaunchKernelGGL(stage_kernel<1>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink, share);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
@@ -110,8 +119,8 @@ int main() {
             }
             std::sort(h.begin(), h.end());
             const double bytes = (double)WINDOW * ITERS;
-            printf("%-10s %d issuing waves: %6.1f B/clk/CU (median CU, s_memtime), %6.1f GB/s per CU, %5.2f TB/s chip (event time %.3f ms)\n",
-                   mode == 0 ? "LDS-DMA" : "registers", nissue, bytes / (double)h[cus / 2], bytes / (best_ms * 1e-3) / 1e9,
+            printf("%s %-10s %d issuing waves: %6.1f B/clk/CU (median CU, s_memtime), %6.1f GB/s per CU, %5.2f TB/s chip (event time %.3f ms)\n",
+                   share == 0 ? "own window   " : share == 1 ? "SHARED window" : share == 2 ? "shared+rotate" : "3 shared:1 own", mode == 0 ? "LDS-DMA" : "registers", nissue, bytes / (double)h[cus / 2], bytes / (best_ms * 1e-3) / 1e9,
                    bytes * cus / (best_ms * 1e-3) / 1e12, best_ms);
         }
     return 0;

@@ -1,0 +1,40 @@
+"""One layer's weight gradient, launched N times (for rocprofv3 --pmc passes: the program itself goes behind `--`).
+   python3 tools/run_wgrad.py [tower|p3|res4|res3|res5] [launches]"""
+import ctypes as C, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch, bench
+L = importlib.import_module(bench.PKG + "._lib")
+SHAPES = {"tower": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 256), "p3": ([(100, 167)], 256, 256),
+          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512)}
+name = sys.argv[1] if len(sys.argv) > 1 else "tower"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+levels, cin, cout = SHAPES[name]
+B = bench.BATCH
+h = L.Handle(0)
+d = L.ConvDesc()
+d.ngroups, d.batch, d.dtype = len(levels), B, 0
+d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
+d.Crun = d.pix_stride = cin
+d.sy = d.sx = 1; d.pad_t = d.pad_l = 1; d.out_ld = cout
+keep = []
+g0 = torch.Generator(device="cuda").manual_seed(1)
+for gi, (H, W) in enumerate(levels):
+    x = torch.randn(B, H, W, cin, device="cuda", generator=g0).to(torch.bfloat16); dy = torch.randn(B, H, W, cout, device="cuda", generator=g0).to(torch.bfloat16)
+    keep += [x, dy]
+    g = L.ConvGroup()
+    g.in_, g.in_elems, g.in_img_stride, g.in_row_stride = x.data_ptr(), x.numel(), H * W * cin, W * cin
+    g.Hin, g.Win, g.Hout, g.Wout = H, W, H, W
+    g.out, g.out_elems, g.out_img_stride = dy.data_ptr(), dy.numel(), H * W * cout
+    d.g[gi] = g
+dW = torch.zeros(cout, 9 * cin, device="cuda"); db = torch.zeros(cout, device="cuda")
+wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d)); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+h.check(L.lib.rtn_conv2d_wgrad_rowinfo(h.raw, C.byref(d), ws.data_ptr(), wsb))
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(n):
+    h.check(L.lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+e.record(); torch.cuda.synchronize()
+flops = 2.0 * sum(H * W for H, W in levels) * B * cout * 9 * cin
+ms = s.elapsed_time(e) / n
+print("%s wgrad: %.4f ms per launch (%.0f TF/s), workspace %.1f MB, impl %d" % (name, ms, flops / ms / 1e9, wsb / 1e6, L.lib.rtn_debug_last_wgrad_impl(h.raw)))
