@@ -53,10 +53,13 @@ def main():
             line = line.strip()
             if line.startswith("{") and '"roofline"' in line:
                 bench_launches = json.loads(line)["roofline"]["launches_per_step"]
-    try:
-        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-    except Exception:
-        commit = "unknown"
+    import os
+    commit = os.environ.get("RTN_GIT_COMMIT")             # the GPU box has no .git: the collecting script passes the commit
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = "unknown"
     json.dump({"_how": __doc__, "git_commit": commit, "batch8_passes": passes, "bench_launches_per_step": bench_launches,
                "kernels": kernels,
                "conv_total": {"launches_per_step": n, "fetch_bytes_per_step": fb, "write_bytes_per_step": wb,
