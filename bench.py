@@ -354,7 +354,7 @@ def main():
             return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
         flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         stem_op = [op for op in active if op[0] == "stem"]
-        stem_2a = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "res2a_branch2a"] if (stem_op and len(stem_op[0]) > 7) else []
+        stem_2a = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "res2a_branch2a"] if (stem_op and stem_op[0][7] is not None) else []
         if stem_2a:                                                    # res2a_branch2a runs inside the stem kernel: its FLOPs still count
             flops_step += conv_flops(stem_2a[0][1], BATCH)
         ms_per_step = 1e3 * elapsed / args.steps

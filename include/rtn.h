@@ -260,7 +260,10 @@ int rtn_maxpool3x3s2_tfsame_bwd(rtn_handle_t h, const void* x, const void* dy, v
                                 int C, float* scratch_f32, int relu_mask /* also zero dx where x <= 0 (x is a ReLU output) */);
 
 /* Training-mode pool1: the forward also records the winning tap (kh*3+kw, first maximum in scan order) per output element
- * (idx: B*Hout*Wout*C bytes) and the backward is an atomic-free gather over the <= 4 windows that contain an input pixel. */
+ * (idx: B*Hout*Wout*C bytes) and the backward is an atomic-free gather over the <= 4 windows that contain an input pixel.
+ * relu_mask of the backward: 0 none; 1: x = the pool's INPUT [B][Hin][Win][C] (a ReLU output), dx zeroed where x <= 0; 2: x = the
+ * pool's OUTPUT [B][Hout][Wout][C]: a window passes its gradient only when its maximum is > 0 - the same mask, for a forward that
+ * never wrote the pool's input (rtn_stem_conv_pool_branch2a with pool_idx). */
 int rtn_maxpool3x3s2_tfsame_fwd_idx(rtn_handle_t h, const void* in, void* out, uint8_t* idx, int dtype, int B, int Hin, int Win, int C);
 int rtn_maxpool3x3s2_tfsame_bwd_idx(rtn_handle_t h, const void* dy, const uint8_t* idx, const void* x, void* dx, int dtype,
                                     int B, int Hin, int Win, int C, int relu_mask);
@@ -308,9 +311,12 @@ int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const
 /* The same kernel with the first bottleneck's branch2a appended (keras_resnet res2a_branch2a 1x1 64 -> 64 + bn2a_branch2a + ReLU,
  * model/defineModel.py:376-380): a_out [B][H2][W2][64] bf16 = relu(w2a . pool1 + b2a), computed from the pooled pixels while they
  * are in registers.  w2a: [>= 64][64] bf16 K-contiguous (BN folded), b2a: f32 [64].  `out` (pool1) is still written: the block's
- * projection shortcut reads it. */
+ * projection shortcut reads it.  pool_idx (optional, u8 [B][H2][W2][64]): the winning tap kh * 3 + kw of every pooled element, as
+ * rtn_maxpool3x3s2_tfsame_fwd_idx records it - the training forward then needs neither conv1's output nor a pooling launch
+ * (rtn_maxpool3x3s2_tfsame_bwd_idx with relu_mask = 2 takes the ReLU mask from pool1 itself).  a_out may be NULL when pool_idx is given. */
 int rtn_stem_conv_pool_branch2a(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
-                                const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out);
+                                const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out,
+                                uint8_t* pool_idx);
 
 /* ---- MaxPool 3x3 / 2, TF 'same' (keras_resnet pool1; -inf padding) ----------------- */
 int rtn_maxpool3x3s2_tfsame_fwd(rtn_handle_t h, const void* in, void* out, int dtype,

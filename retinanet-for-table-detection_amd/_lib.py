@@ -125,7 +125,7 @@ SIGNATURES = {
     "rtn_adam_clipnorm_step_segments": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I64, _I64, _F, _F, _F, _F, _P, _I, _P, _I64, _F, _F]),
     "rtn_stem_pack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I]),
     "rtn_stem_conv_pool": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I]),
-    "rtn_stem_conv_pool_branch2a": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "rtn_stem_conv_pool_branch2a": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "rtn_maxpool3x3s2_tfsame_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     "rtn_relu": (_I, [_P, _P, _P, _I, _I64]),
     "rtn_generate_anchors": (_I, [_D, C.POINTER(_D), _I, C.POINTER(_D), _I, C.POINTER(_D)]),

@@ -960,23 +960,29 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const char* __rest
                 const uint4 gq = *reinterpret_cast<const uint4*>(dy + o * 16);
                 const unsigned g4[4] = {gq.x, gq.y, gq.z, gq.w};
                 const unsigned char* ip = idx + o * CE;
+                // relu_mask == 2: x is the POOLED tensor: the winner's value IS the window's maximum, so "x > 0 at the winner" is
+                // "pooled > 0" (the fused stem kernel never writes the pre-pool tensor)
+                uint4 yq = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                if (relu_mask == 2) yq = *reinterpret_cast<const uint4*>(x + o * 16);
+                const unsigned y4[4] = {yq.x, yq.y, yq.z, yq.w};
                 if constexpr (ES == 2) {
                     const uint2 iq = *reinterpret_cast<const uint2*>(ip);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const unsigned char a = (unsigned char)(((j < 4 ? iq.x : iq.y) >> (8 * (j & 3))) & 0xffu);
                         const float g = (j & 1) ? __uint_as_float(g4[j >> 1] & 0xffff0000u) : __uint_as_float(g4[j >> 1] << 16);
-                        if (a == tap) s[j] += g;
+                        const float yv = (j & 1) ? __uint_as_float(y4[j >> 1] & 0xffff0000u) : __uint_as_float(y4[j >> 1] << 16);
+                        if (a == tap && yv > 0.f) s[j] += g;
                     }
                 } else {
                     const unsigned iq = *reinterpret_cast<const unsigned*>(ip);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if ((unsigned char)((iq >> (8 * j)) & 0xffu) == tap) s[j] += __uint_as_float(g4[j]);
+                        if ((unsigned char)((iq >> (8 * j)) & 0xffu) == tap && (relu_mask != 2 || __uint_as_float(y4[j]) > 0.f)) s[j] += __uint_as_float(g4[j]);
                 }
             }
         }
-        if (relu_mask) {
+        if (relu_mask == 1) {
             const uint4 xq = *reinterpret_cast<const uint4*>(x + i * 16);
             const unsigned x4[4] = {xq.x, xq.y, xq.z, xq.w};
             if constexpr (ES == 2) {

@@ -49,6 +49,7 @@ struct StemParams {
     const char* w2a;            // A2: res2a_branch2a filters [>= 64][64] bf16 (BN folded), K-contiguous
     const float* b2a;           // A2: its folded BN shift [64]
     unsigned short* a_out;      // A2: [B][H2][W2][64] bf16
+    unsigned char* idx;         // IDX: [B][H2][W2][64] u8, the winning tap kh * 3 + kw of every pooled element (training: the pool's backward)
     unsigned xp_bytes;
     int Hp, Wp, H1, W1, H2, W2, pool_pt, pool_pl;
     int tiles_x, tiles_y, ntiles;
@@ -66,7 +67,7 @@ __device__ __forceinline__ int stem_perm_row(int rho) {
 // this tile's MFMAs and written to LDS after this tile's pooling.  A2: the pooled pixels (8 channels per lane, which is exactly a
 // B-operand fragment of the transposed product) also go through res2a_branch2a (1x1, 64 -> 64, BN, ReLU; keras_resnet bottleneck
 // behind model/defineModel.py:376-380): the layer's launch and its read of pool1 disappear.
-template <bool A2>
+template <bool A2, bool IDX>
 __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* wl = lds;                      // filters, resident
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
         for (int h = 0; h < 2; ++h) {
             const int cg = 4 * h + kq;
             float mx[8];
+            unsigned am[8];                                // IDX: first maximum in (kh, kw) scan order, as rtn_maxpool3x3s2_tfsame_fwd_idx records it
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+            for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 255u; }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -225,10 +227,22 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
                     const unsigned w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        mx[2 * e] = fmaxf(mx[2 * e], __uint_as_float(w4[e] << 16));
-                        mx[2 * e + 1] = fmaxf(mx[2 * e + 1], __uint_as_float(w4[e] & 0xffff0000u));
+                        const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+                        if (IDX) {
+                            if (lo > mx[2 * e]) { mx[2 * e] = lo; am[2 * e] = (unsigned)(dy * 3 + dx); }
+                            if (hi > mx[2 * e + 1]) { mx[2 * e + 1] = hi; am[2 * e + 1] = (unsigned)(dy * 3 + dx); }
+                        } else {
+                            mx[2 * e] = fmaxf(mx[2 * e], lo);
+                            mx[2 * e + 1] = fmaxf(mx[2 * e + 1], hi);
+                        }
                     }
                 }
+            if (IDX && live) {
+                uint2 iq;
+                iq.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+                iq.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+                *reinterpret_cast<uint2*>(p.idx + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + cg * 8)) = iq;
+            }
             uint4 o;
             o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
             o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
 }  // namespace
 
 static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows, const float* bias, void* out,
-                       int B, int H, int W, const void* w2a, const float* b2a, void* a_out) {
+                       int B, int H, int W, const void* w2a, const float* b2a, void* a_out, uint8_t* idx) {
     if (!h) return RTN_EINVAL;
     rtn_env_sync();
     if (!packed || !w_packed || !out) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: null pointer");
@@ -280,6 +294,7 @@ static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const
     const bool a2 = a_out != nullptr;
     if (a2 && (!w2a || !b2a || ((uintptr_t)w2a & 15) || ((uintptr_t)a_out & 15) || ((uintptr_t)b2a & 3) || a_out == out))
         return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: a_out needs aligned branch2a filters / shifts and its own buffer");
+    if (idx && ((uintptr_t)idx & 7)) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: pool_idx must be 8-byte aligned");
     const int H1 = (H - 1) / 2 + 1, W1 = (W - 1) / 2 + 1;              // ZeroPadding2D(3) + 7x7/2 'valid'
     if (Hp < 2 * (H1 - 1) + 7 || Wp < 2 * (W1 - 1) + 8) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool: packed image %dx%d too small for %dx%d", Hp, Wp, H, W);
     const long long bytes = (long long)B * Hp * Wp * 8;
@@ -289,7 +304,7 @@ static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const
     StemParams p;
     memset(&p, 0, sizeof(p));
     p.xp = (const char*)packed; p.wk = (const char*)w_packed; p.bias = bias; p.out = (unsigned short*)out;
-    p.w2a = (const char*)w2a; p.b2a = b2a; p.a_out = (unsigned short*)a_out;
+    p.w2a = (const char*)w2a; p.b2a = b2a; p.a_out = (unsigned short*)a_out; p.idx = idx;
     p.xp_bytes = (unsigned)bytes;
     p.Hp = Hp; p.Wp = Wp; p.H1 = H1; p.W1 = W1; p.H2 = H2; p.W2 = W2;
     p.pool_pt = (pth > 0 ? pth : 0) / 2; p.pool_pl = (ptw > 0 ? ptw : 0) / 2;
@@ -300,25 +315,30 @@ static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const
     long long grid = 2ll * (h->num_cus > 0 ? h->num_cus : 256);        // two workgroups per CU (LDS_BYTES each)
     { const int gl = rtn_env_int("RTN_STEM_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: many tiles per workgroup on small images
     if (grid > ntiles) grid = ntiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_A2));
-        attr_set = true;
-    }
-    if (a2) hipLaunchKernelGGL(stem_fused_kernel<true>, dim3((unsigned)grid), dim3(256), LDS_BYTES_A2, h->stream, p);
-    else    hipLaunchKernelGGL(stem_fused_kernel<false>, dim3((unsigned)grid), dim3(256), LDS_BYTES, h->stream, p);
+#define RTN_STEM_LAUNCH(A2_, IDX_, LDSB)                                                                       \
+    do {                                                                                                      \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) {                                                                                      \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<A2_, IDX_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL((stem_fused_kernel<A2_, IDX_>), dim3((unsigned)grid), dim3(256), LDSB, h->stream, p); \
+    } while (0)
+    if (a2) { if (idx) RTN_STEM_LAUNCH(true, true, LDS_BYTES_A2); else RTN_STEM_LAUNCH(true, false, LDS_BYTES_A2); }
+    else    { if (idx) RTN_STEM_LAUNCH(false, true, LDS_BYTES); else RTN_STEM_LAUNCH(false, false, LDS_BYTES); }
+#undef RTN_STEM_LAUNCH
     RTN_CHECK_LAUNCH(h, "stem_fused_kernel");
     return RTN_OK;
 }
 
 extern "C" int rtn_stem_conv_pool(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
                                   const float* bias, void* out, int B, int H, int W) {
-    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, nullptr, nullptr, nullptr);
+    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int rtn_stem_conv_pool_branch2a(rtn_handle_t h, const void* packed, int Hp, int Wp, const void* w_packed, int w_rows,
-                                           const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out) {
-    if (h && !a_out) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool_branch2a: null a_out");
-    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, w2a, b2a, a_out);
+                                           const float* bias, void* out, int B, int H, int W, const void* w2a, const float* b2a, void* a_out,
+                                           uint8_t* pool_idx) {
+    if (h && !a_out && !pool_idx) return rtn_fail(h, RTN_EINVAL, "stem_conv_pool_branch2a: neither a_out nor pool_idx (use rtn_stem_conv_pool)");
+    return stem_launch(h, packed, Hp, Wp, w_packed, w_rows, bias, out, B, H, W, w2a, b2a, a_out, pool_idx);
 }

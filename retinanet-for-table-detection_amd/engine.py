@@ -86,6 +86,9 @@ class Engine:
         self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
         self.fuse_stem = os.environ.get("RTN_FUSE_STEM", "1") != "0"        # inference/bf16: conv1+ReLU+pool1 in one kernel
         self.fuse_stem_2a = os.environ.get("RTN_FUSE_STEM_2A", "1") != "0"  # ... which also applies res2a_branch2a to the pooled pixels
+        # training/bf16: the same kernel also records the pool's winning taps; conv1's output is never written and the pool's
+        # backward takes its ReLU mask from pool1 (trainer.py)
+        self.fuse_stem_train = os.environ.get("RTN_FUSE_STEM_TRAIN", "1") != "0"
         self.fuse_shortcut = os.environ.get("RTN_FUSE_SHORTCUT", "1") != "0"  # inference: branch1 folded into branch2c (dual-source GEMM)
         # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
         # + shortcut -> the next block's branch2a)
@@ -392,7 +395,7 @@ class Engine:
         keep.append(pool_idx)
         ops.append(("pool", c1, x, (B, H1, W1, 64), pool_idx))
         # inference, bf16: the three stem ops above collapse into one kernel (rtn_stem_conv_pool)
-        stem_fused = ("stem", x, (B, H, W), wk, bk, xp, (Hp, Wp))
+        stem_fused = ("stem", x, (B, H, W), wk, bk, xp, (Hp, Wp), None, pool_idx)       # [7]: (a_out, w2a, b2a) with fuse_stem == 2
         n_stem_ops = len(ops)
         # ---- bottleneck stages
         feats = []
@@ -547,7 +550,7 @@ class Engine:
                         fb0 = first_blocks[0]
                         if fs == 2 and fb0["f"] == 64 and fb0["step"] == 1 and fb0["i_2a"] is not None and v[fb0["i_2a"]] is not None:
                             w2a, b2a = self.w[fb0["n2a"]][:2]             # the pooled pixels go through res2a_branch2a before they leave the registers
-                            sf = stem_fused + ((fb0["a"], w2a, b2a),)
+                            sf = stem_fused[:7] + ((fb0["a"], w2a, b2a), stem_fused[8])
                             v[fb0["i_2a"]] = None
                         v = [v[0], sf] + v[n_stem_ops:]                  # pack, then conv1 + ReLU + pool1 as one launch
                     v = [op for op in v if op is not None]
@@ -575,7 +578,7 @@ class Engine:
         if kind == "pack":
             return [], [op[1].data_ptr()]
         if kind == "stem":
-            return [op[5].data_ptr()], [op[1].data_ptr()] + ([op[7][0].data_ptr()] if len(op) > 7 else [])
+            return [op[5].data_ptr()], [op[1].data_ptr(), op[8].data_ptr()] + ([op[7][0].data_ptr()] if op[7] is not None else [])
         if kind == "dual":
             return [t.data_ptr() for t in op[4]["xs"]], [t.data_ptr() for t in op[4]["ys"]]
         if kind == "bneck":
@@ -695,15 +698,15 @@ class Engine:
         return plan["regression"], plan["classification"]
 
     def _fused(self):
-        """(stem fused: 0 / 1 / 2 = with res2a_branch2a, shortcut fused, 64-channel bottleneck blocks fused) or None.  Training keeps conv1 / pool1 separate (the
-        backward needs conv1's output and the pooling argmax) and every bottleneck tensor (the backward reads them); the folded
+        """(stem fused: 0 / 1 / 2 = with res2a_branch2a, shortcut fused, 64-channel bottleneck blocks fused) or None.  Training keeps
+        every bottleneck tensor (the backward reads them) and, in fp32, conv1 / pool1 separate; the folded
         shortcut is used there too - no gradient needs the shortcut TENSOR, only its input and filters.  The fused stem and the fused
         bottleneck exist for bf16 only; the fp8 plan keeps its own branch2a / branch2b pairing."""
-        infer16 = self.dtype == "bf16" and not self.training
+        stem16 = self.dtype == "bf16" and (not self.training or self.fuse_stem_train)
         fk = 0
         if self.fuse_bottleneck and self.dtype == "bf16" and not self._fp8_on():
             fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
-        fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and infer16) else 0
+        fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and stem16) else 0
         key = (fs, self.fuse_shortcut, fk)
         return key if any(key) else None
 
@@ -729,11 +732,13 @@ class Engine:
             h.check(lib.rtn_quantize_fp8(h.raw, op[1].data_ptr(), self.rdt, op[2].data_ptr(), op[1].numel(), op[3]))
         elif kind == "stem":
             Bn, Hn, Wn = op[2]
-            if len(op) > 7:                              # + res2a_branch2a on the pooled pixels
-                a_out, w2a, b2a = op[7]
+            if op[7] is not None or self.training:       # + res2a_branch2a on the pooled pixels; training: + the pool's winning taps
+                a_out, w2a, b2a = op[7] if op[7] is not None else (None, None, None)
                 h.check(lib.rtn_stem_conv_pool_branch2a(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
-                                                        op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn, w2a.data_ptr(), b2a.data_ptr(),
-                                                        a_out.data_ptr()))
+                                                        op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn,
+                                                        w2a.data_ptr() if w2a is not None else None, b2a.data_ptr() if b2a is not None else None,
+                                                        a_out.data_ptr() if a_out is not None else None,
+                                                        op[8].data_ptr() if self.training else None))
             else:
                 h.check(lib.rtn_stem_conv_pool(h.raw, op[5].data_ptr(), op[6][0], op[6][1], op[3].data_ptr(), op[3].shape[0],
                                                op[4].data_ptr(), op[1].data_ptr(), Bn, Hn, Wn))

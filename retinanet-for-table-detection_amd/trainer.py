@@ -344,7 +344,7 @@ class Trainer:
                 x, y = op[1], op[2]
                 dy = grads.get(tid(y))
                 done[tid(x)] = done.get(tid(x), 0) + 1
-                bops.append(("poolbwd", x, dy, gbuf(x), op[3], op[4]))
+                bops.append(("poolbwd", x, dy, gbuf(x), op[3], op[4], y))      # y: the pooled tensor (the fused stem's ReLU mask)
                 gstate[tid(x)] = "buf"
         loss_ws = torch.empty(L.lib.rtn_retina_loss_workspace_bytes(B * N), dtype=torch.uint8, device=dev)
         bias_bops = [i for i, b in enumerate(bops) if b[0] == "wgrad" and b[4] is not None]
@@ -369,7 +369,7 @@ class Trainer:
         if kind == "upbwd":
             return [b[1].data_ptr()] + ([b[2].data_ptr()] if b[4] else []), [b[2].data_ptr()]
         if kind == "poolbwd":
-            return [b[1].data_ptr(), b[2].data_ptr(), b[5].data_ptr()], [b[3].data_ptr()]
+            return [b[1].data_ptr(), b[2].data_ptr(), b[5].data_ptr(), b[6].data_ptr()], [b[3].data_ptr()]
         d = b[1]
         if kind == "wgrad":
             reads = [p_ for i in range(d.ngroups) for p_ in (d.g[i].in_, d.g[i].out)]
@@ -535,8 +535,10 @@ class Trainer:
                 h.check(lib.rtn_upsample_add_bwd(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, Bn, Hd, Wd, Hs, Ws, Cc, b[4]))
             elif kind == "poolbwd":
                 Bn, Hi, Wi, Cc = b[4]
-                h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), b[1].data_ptr(), b[3].data_ptr(), eng.rdt,
-                                                            Bn, Hi, Wi, Cc, 1))
+                # the fused stem (bf16 training forward) never writes conv1's output: the ReLU mask comes from the pooled tensor
+                fused = eng.fuse_stem and eng.fuse_stem_train and eng.dtype == "bf16"
+                h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), (b[6] if fused else b[1]).data_ptr(),
+                                                            b[3].data_ptr(), eng.rdt, Bn, Hi, Wi, Cc, 2 if fused else 1))
             else:
                 raise RuntimeError(kind)
             if lane_on:

@@ -58,7 +58,9 @@ for b in bp["bops"]:
         elif kind == "padcast": h.check(lib.rtn_pad_cast_rows(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, b[3], b[4], b[5]))
         elif kind == "zins": h.check(lib.rtn_zero_insert2(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, *b[3]))
         elif kind == "upbwd": h.check(lib.rtn_upsample_add_bwd(h.raw, b[1].data_ptr(), b[2].data_ptr(), eng.rdt, *b[3], b[4]))
-        elif kind == "poolbwd": h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), b[1].data_ptr(), b[3].data_ptr(), eng.rdt, *b[4], 1))
+        elif kind == "poolbwd":
+            fused = eng.fuse_stem and eng.fuse_stem_train and eng.dtype == "bf16"
+            h.check(lib.rtn_maxpool3x3s2_tfsame_bwd_idx(h.raw, b[2].data_ptr(), b[5].data_ptr(), (b[6] if fused else b[1]).data_ptr(), b[3].data_ptr(), eng.rdt, *b[4], 2 if fused else 1))
     ms = timed(run)
     label = kind + ((":" + (b[3] if kind == "wgrad" else b[-1])) if kind in ("wgrad", "dgrad") else "")
     acc[label] = acc.get(label, 0) + ms
