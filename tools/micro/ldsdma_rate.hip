@@ -34,8 +34,9 @@ constexpr int ITERS = 64;              // sweeps of the window
 // share: 0 = every workgroup sweeps its OWN window; 1 = ALL workgroups sweep the same window in the same piece order (what the weight
 // tiles of the convolution kernels do: 256 CUs request the same lines at the same time); 2 = the same window, but workgroup b starts
 // its sweep at piece (b * 7) mod pieces (the simultaneous requests of different CUs go to different lines / L2 channels)
-template <int MODE>                    // 0 = LDS-DMA, 1 = registers
-__global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned long long* clocks, int nissue, float* sink, int share) {
+//        3 = three pieces of four from the shared window (L2 hits), one from the workgroup's own (memory side)
+template <int MODE, int share>         // MODE 0 = LDS-DMA, 1 = registers
+__global__ __launch_bounds__(512) void stage_kernel(const char* src, unsigned long long* clocks, int nissue, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -97,8 +98,11 @@ int main() {
     hipMemset(src, 1, (size_t)cus * SRCW);
     hipMalloc(&clk, cus * sizeof(unsigned long long));
     hipMalloc(&sink, cus * sizeof(float));
-    hipFuncSetAttribute((const void*)stage_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
-    hipFuncSetAttribute((const void*)stage_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
+    hipFuncSetAttribute((const void*)stage_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
+    hipFuncSetAttribute((const void*)stage_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
+    hipFuncSetAttribute((const void*)stage_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
+    hipFuncSetAttribute((const void*)stage_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
+    hipFuncSetAttribute((const void*)stage_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WINDOW);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%d CUs, %d KiB source window per workgroup staged through %d KiB of LDS, %d sweeps of 64 KiB\n", cus, SRCW / 1024, WINDOW / 1024, ITERS);
@@ -109,8 +113,11 @@ int main() {
             std::vector<unsigned long long> h(cus);
             for (int rep = 0; rep < 5; ++rep) {
                 hipEventRecord(e0);
-                if (mode == 0) hipLaunchKernelGGL(stage_kernel<0>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink, share);
-                else           hipLaunchKernelGGL(stage_kernel<1>, dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink, share);
+                if (mode == 1) hipLaunchKernelGGL((stage_kernel<1, 0>), dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
+                else if (share == 0) hipLaunchKernelGGL((stage_kernel<0, 0>), dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
+                else if (share == 1) hipLaunchKernelGGL((stage_kernel<0, 1>), dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
+                else if (share == 2) hipLaunchKernelGGL((stage_kernel<0, 2>), dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
+                else                 hipLaunchKernelGGL((stage_kernel<0, 3>), dim3(cus), dim3(512), WINDOW, 0, src, clk, nissue, sink);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 float ms;
