@@ -28,6 +28,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr unsigned G8_OOB = 0xFFFF0000u;              // beyond every descriptor even with the largest uniform offset (K bytes) added
 constexpr int G8_THREADS = 512;
@@ -101,9 +102,20 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // EPI: bit 0 = residual add (the `Add` closing a bottleneck block; accumulated gradient contributions in training), bit 1 = ReLU mask
 // of the tensor being differentiated (rtn_conv2d_dgrad): 16 bytes per lane and row, loaded one row fragment ahead of their use.
-template <int MI, bool STAGGER, bool DUAL, int EPI>
+// NW = 8: 256-column tile (wave tile 16 MI x 128), B ring of two 32 KiB stages, four phases per K step as described above.
+// NW = 4: 128-column tile (wave tile 16 MI x 64) for the N = 128 layers (res3 branch2a and the matching data gradients), which on the
+//   256-column tile spent half of their B staging, fragment reads and MFMAs on zero columns.  TWO phases per K step ({A and B fragments
+//   of one k half | barrier | 4 MI MFMAs | barrier}), B ring of THREE 16 KiB stages: B(s+2) and A(s+2) are both issued in the second
+//   phase of step s (B first: it is L2-resident), into the slots step s-1 read last - one full phase after the lagging wave group's
+//   last read of them - and the step's one wait, vmcnt(2 + MI), retires everything older, i.e. A(s+1) and B(s+1), one phase before
+//   their first read.  A lane ends up with 4 consecutive channels of a pixel (position 16 j + c <-> channel 4 c + j): 8-byte stores.
+template <int MI, bool STAGGER, bool DUAL, int EPI, int NW = 8>
 __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Params p) {
     constexpr int R = 64 * MI;                         // rows of a tile
+    constexpr int CT = 32 * NW;                        // columns of a tile
+    constexpr unsigned BSTG = NW == 8 ? G8_STAGE : G8_STAGE / 2;      // bytes of a B stage
+    constexpr int NBD = NW / 2;                        // 1-KiB staging pieces of a B stage per wave
+    static_assert(NW == 8 || (NW == 4 && !DUAL), "the 128-column instance: single source");
     static_assert(MI >= 2 && MI <= 3, "the bias table lives in the tail of A stage 0: tiles of at most 192 rows");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -160,13 +172,14 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             }
         }
     };
-    unsigned wrow_off[4];
+    unsigned wrow_off[NBD];
     auto b_tile = [&](int T) {
         const int nt = T < p.ntiles ? T - (T / p.ntiles_n) * p.ntiles_n : 0;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < NBD; ++d) {
             const int P = d * 64 + wave * 8 + lr;
-            const int nrow = nt * 256 + (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7);
+            const int nrow = NW == 8 ? nt * 256 + (P >> 7) * 128 + 8 * (P & 15) + ((P >> 4) & 7)
+                                     : nt * 128 + (P >> 6) * 64 + 4 * (P & 15) + ((P >> 4) & 3);
             wrow_off[d] = (unsigned)nrow * (unsigned)p.Kbytes + (unsigned)sc * 16u;
         }
     };
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
         const int row = wm * (16 * MI) + i * 16 + lrow;
         arow[i] = (unsigned)(row * 128 + ((kq ^ (row & 7)) << 4));
     }
-    const unsigned b_lane = G8_B_BASE + (unsigned)((wn * 128 + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
+    const unsigned b_lane = G8_B_BASE + (unsigned)((wn * (16 * NW) + lrow) * 128 + ((kq ^ (lrow & 7)) << 4));
 
     // ---- prologue: A tiles of steps 0 and 1, B tile of step 0
     int ta = tile, ka = 0;          // A cursor: the step whose A tile is staged next (two ahead of the multiply)
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     }
 #define G8_ADV_B()                                                                                   \
     {                                                                                                \
-        b_st ^= G8_STAGE;                                                                            \
+        if (NW == 8) b_st ^= G8_STAGE; else b_st = b_st == 2 * BSTG ? 0u : b_st + BSTG;              \
         if (++kb == nk) { kb = 0; tb += tstride; b_tile(tb); }                                       \
     }
 #pragma unroll
@@ -210,14 +223,17 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
         G8_ADV_A()
     }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) stage_b(d, kb, G8_B_BASE + b_st);
-    G8_ADV_B()
+    for (int s = 0; s < (NW == 8 ? 1 : 2); ++s) {      // the 128-column instance runs its B stream two steps ahead, like A
+#pragma unroll
+        for (int d = 0; d < NBD; ++d) stage_b(d, kb, G8_B_BASE + b_st);
+        G8_ADV_B()
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the LDS-DMA pieces and this wave's bias stores
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();                      // also publishes the bias table
 
     unsigned a_cur = 0, b_cur = 0;                     // ring slots of the step being multiplied
-    f32x4 acc[MI][8];
+    f32x4 acc[MI][NW];
     const float* bias_l = reinterpret_cast<const float*>(lds + G8_BIAS_OFF);
 
 #define G8_LDA(KS)                                                                                   \
@@ -240,22 +256,40 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
 
     while (tile < p.ntiles) {
         const int mt = tile / p.ntiles_n, nt = tile - mt * p.ntiles_n;
-        const int m0 = mt * R, n0 = nt * 256;
+        const int m0 = mt * R, n0 = nt * CT;
         {
-            const float* bp = bias_l + n0 + wn * 128 + 8 * lrow;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+            const float* bp = bias_l + n0 + wn * (16 * NW) + NW * lrow;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + (NW == 8 ? 4 : 0));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[i][j] = (f32x4){b0[j], b0[j], b0[j], b0[j]};
-                    acc[i][4 + j] = (f32x4){b1[j], b1[j], b1[j], b1[j]};
+                    if (NW == 8) acc[i][(NW == 8 ? 4 : 0) + j] = (f32x4){b1[j], b1[j], b1[j], b1[j]};
                 }
             }
         }
 #pragma unroll 1
         for (int k = 0; k < nk; ++k) {
             uint4 fa[MI], fb[4];
+            if constexpr (NW == 4) {
+                // phase 1: fragments of k half 0, no staging (the stages freed by step k-1 may still be read by the lagging wave group)
+                G8_LDA(0) G8_LDB(0, 0)
+                G8_MFMA(0)
+                // phase 2: fragments of k half 1; B(s+2), then A(s+2); everything older has landed after the wait
+                G8_LDA(1) G8_LDB(1, 0)
+#pragma unroll
+                for (int d = 0; d < NBD; ++d) stage_b(d, kb, G8_B_BASE + b_st);
+                G8_ADV_B()
+#pragma unroll
+                for (int i = 0; i < MI; ++i) stage_a(i, ka, a_st);
+                G8_ADV_A()
+                if (MI == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                G8_MFMA(0)
+                a_cur = a_cur == 2 * G8_STAGE ? 0u : a_cur + G8_STAGE;
+                b_cur = b_cur == 2 * BSTG ? 0u : b_cur + BSTG;
+            } else {
             // phase 1: no staging (the B stage freed by step k-1 may still be read by the lagging wave group)
             G8_LDA(0) G8_LDB(0, 0)
             G8_MFMA(0)
@@ -266,8 +300,8 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             G8_MFMA(1)
             // phase 3: second half of B(s+1), first piece of A(s+2)
             G8_LDA(1) G8_LDB(1, 0)
-            stage_b(2, kb, G8_B_BASE + b_st);
-            stage_b(3, kb, G8_B_BASE + b_st);
+            stage_b(NBD - 2, kb, G8_B_BASE + b_st);
+            stage_b(NBD - 1, kb, G8_B_BASE + b_st);
             G8_ADV_B()
             stage_a(0, ka, a_st);
             G8_MFMA(0)
@@ -281,6 +315,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             G8_MFMA(1)
             a_cur = a_cur == 2 * G8_STAGE ? 0u : a_cur + G8_STAGE;
             b_cur ^= G8_STAGE;
+            }
         }
         // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane
         {
@@ -290,10 +325,11 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 (void*)((EPI & 1) ? p.res : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 1) ? p.res_bytes : 0u)), 0x00020000);
             const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((EPI & 2) ? p.mask : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? p.mask_bytes : 0u)), 0x00020000);
-            const int ncol = n0 + wn * 128 + 8 * lrow;
+            const int ncol = n0 + wn * (16 * NW) + NW * lrow;
             const bool col_ok = ncol < p.N;
             // residual / mask rows of every row fragment: all MI x 4 loads of a wave go out before the first is used (these layers are
-            // bound by their pixel traffic: more loads in flight per wave; RTN_G8_EPI_DEPTH=1 at compile time: fragment i + 1 only)
+            // bound by their pixel traffic: more loads in flight per wave).  NW = 4: 8 bytes per lane and row instead of 16.
+            constexpr int NWD = NW / 2;                       // dwords per lane and row
             u32x4 rq[MI][4], mq[(EPI & 2) ? MI : 1][4];
             auto fetch = [&](int i) {
                 const int par = i, parm = (EPI & 2) ? i : 0;
@@ -312,9 +348,15 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                             sx_ = sx_ < p.Wres - 1 ? sx_ : p.Wres - 1;
                             rrow = (unsigned)b * p.res_img_stride + (unsigned)(sy_ * p.Wres + sx_) * (unsigned)p.res_ld;
                         }
-                        rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (int)(ok ? (rrow + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                        const int roff = (int)(ok ? (rrow + (unsigned)ncol) * 2u : G8_OOB);
+                        if (NW == 8) rq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, roff, 0, 0);
+                        else { const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, roff, 0, 0); rq[par][r] = (u32x4){t2.x, t2.y, 0u, 0u}; }
                     }
-                    if (EPI & 2) mq[parm][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB), 0, 0);
+                    if (EPI & 2) {
+                        const int moff = (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB);
+                        if (NW == 8) mq[parm][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, moff, 0, 0);
+                        else { const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc, moff, 0, 0); mq[parm][r] = (u32x4){t2.x, t2.y, 0u, 0u}; }
+                    }
                 }
             };
             if (EPI) {
@@ -326,13 +368,13 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
-                    float v[8];
+                    float v[NW];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r];
+                    for (int j = 0; j < NW; ++j) v[j] = acc[i][j][r];
                     if (EPI) {
                         const u32x4 rw = rq[i][r], mw = mq[(EPI & 2) ? i : 0][r];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < NWD; ++j) {
                             const unsigned mj = (EPI & 2) ? mw[j] : 0x3f803f80u, rj = (EPI & 1) ? rw[j] : 0u;
                             const bool keep_lo = __uint_as_float(mj << 16) > 0.f, keep_hi = __uint_as_float(mj & 0xffff0000u) > 0.f;
                             if ((EPI & 2) && p.mask_pre) { if (!keep_lo) v[2 * j] = 0.f; if (!keep_hi) v[2 * j + 1] = 0.f; }
@@ -342,13 +384,20 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                     }
                     if (p.relu) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                        for (int j = 0; j < NW; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                     }
-                    u32x4 o;
-                    o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
                     const unsigned off = (col_ok && m < p.M) ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : G8_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
-                    RTN_STORE_GUARD(o)
+                    if constexpr (NW == 8) {
+                        u32x4 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, (int)off, 0, 0);
+                        RTN_STORE_GUARD(o)
+                    } else {
+                        u32x2 o;
+                        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+                        __builtin_amdgcn_raw_buffer_store_b64(o, out_rsrc, (int)off, 0, 0);
+                        asm volatile("s_nop 3" :: "v"(o.x), "v"(o.y));
+                    }
                 }
             }
         }
@@ -434,7 +483,7 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     const long long Kbytes = Kel * 2;
     if (Kbytes > 16384 || Kbytes * d->N >= (long long)G8_OOB) return 1;
     const int cus = h->num_cus > 0 ? h->num_cus : 256;
-    const int ntn = (d->N + 255) / 256;
+    const int ntn = n128 ? 1 : (d->N + 255) / 256;         // N = 128: the 128-column instance, one column tile
     int mi = mi_force;
     if (mi < 2 || mi > 3) {                            // tile height by rounds x (rows + a fixed per-tile cost)
         double best = 0;
@@ -493,7 +542,26 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         else if (epi == 2) RTN_G8_LAUNCH(M_, true, false, 2);                                            \
         else RTN_G8_LAUNCH(M_, true, false, 3);                                                          \
     } while (0)
-    if (mi == 3) RTN_G8_PICK(3); else RTN_G8_PICK(2);
+#define RTN_G8_LAUNCH4(M_, EP)                                                                           \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, true, false, EP, 4>,       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_gemm8_kernel<M_, true, false, EP, 4>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
+    } while (0)
+#define RTN_G8_PICK4(M_)                                                                                 \
+    do {                                                                                                 \
+        if (epi == 0) RTN_G8_LAUNCH4(M_, 0); else if (epi == 1) RTN_G8_LAUNCH4(M_, 1);                   \
+        else if (epi == 2) RTN_G8_LAUNCH4(M_, 2); else RTN_G8_LAUNCH4(M_, 3);                            \
+    } while (0)
+    const bool narrow = n128 && !s2 && stagger && rtn_env_int("RTN_CONV_G8_NARROW", 1) != 0;      // 0: N = 128 on the 256-column tile (A/B)
+    if (narrow) { if (mi == 3) RTN_G8_PICK4(3); else RTN_G8_PICK4(2); }
+    else if (mi == 3) RTN_G8_PICK(3); else RTN_G8_PICK(2);
+#undef RTN_G8_PICK4
+#undef RTN_G8_LAUNCH4
 #undef RTN_G8_PICK
 #undef RTN_G8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_gemm8_kernel");

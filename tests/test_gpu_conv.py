@@ -339,6 +339,36 @@ def test_gemm8_residual_forms_and_half_width(pkg, handle, monkeypatch, levels, c
     check(gots, wants, ld, n, "bf16")
 
 
+@pytest.mark.parametrize("levels,cin,stride,res,B,grid,mi", [
+    ([(40, 67)], 512, 1, None, 2, 0, 0),           # res3 branch2a: 8 K steps, default grid and tile height
+    ([(40, 67)], 512, 1, None, 2, 3, 2),           # ... 3 workgroups walk 14 tiles of 128 rows each: ring turnover across tiles
+    ([(33, 51)], 256, 2, None, 3, 2, 3),           # res3a branch2a: stride-2 'valid' sampling, 4 K steps
+    ([(17, 23)], 64, 1, "same", 3, 1, 2),          # ONE K step per tile (the B ring runs two tiles ahead), residual epilogue (8-byte loads)
+    ([(25, 42)], 1024, 1, "same", 2, 5, 3),        # 16 K steps, residual
+])
+def test_gemm8_narrow_instance_for_128_columns(pkg, handle, monkeypatch, levels, cin, stride, res, B, grid, mi):
+    """conv_gemm8_kernel<.., NW = 4>: the 128-column tile for the N = 128 layers (res3 branch2a behind model/defineModel.py:376-380 and
+    the matching data gradients): two phases per K step, B ring of three 16 KiB stages, 8-byte register stores.  Against the float64
+    product of the bf16 operands, BIT FOR BIT against the same layer on the 256-column tile (RTN_CONV_G8_NARROW=0: the same k order and
+    the same bias-initialised accumulators), and bit for bit against itself on repeated launches."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_G8_MI", str(mi))
+    flags = L.CONV_RELU | (L.CONV_RES_SAME if res == "same" else 0)
+    out = {}
+    for narrow in ("1", "0", "1"):
+        monkeypatch.setenv("RTN_CONV_G8_NARROW", narrow)
+        gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, 128, 1, stride, 0, flags, res, B=B, seed=170 + grid)
+        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+        check(gots, wants, ld, n, "bf16")
+        out.setdefault(narrow, []).append(gots)
+    for a, b in zip(out["1"][0], out["1"][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert torch.equal(a, b), "narrow and wide instances differ by %.3e" % float((a - b).abs().max())
+
+
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
