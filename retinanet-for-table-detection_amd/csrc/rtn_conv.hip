@@ -1840,29 +1840,64 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const T* __restrict__ w
         wd[i] = v;
     }
 }
-// All layers in one launch.  table[l] = {src, dst, N, KH, KW, Cin, Crun, rows_d, first flat element of layer l, -}; the flat
-// element index is searched in the prefix column (binary search, ~7 steps for a ResNet-50 RetinaNet).
+// All layers in one launch.  table[l] = {src, dst, N, KH, KW, Cin, Crun, rows_d, first flat element of layer l, -}.
+// Per tap the repack is a TRANSPOSE of the (filter n, channel c) plane: w_d[c][tap'][n] = w[n][tap][c].  Round 2 did it one element
+// per thread with a 2-byte read every K elements apart (0.28 ms per optimizer step for 72 MB); now a workgroup moves 64 x 64 tiles
+// through LDS - 128-byte runs of c on the way in, 128-byte runs of n on the way out - and finds its tiles in a per-layer prefix that
+// every workgroup builds once from the table (the API stays as it was: the host only knows the table's device address).
+constexpr int PK_T = 64;
+constexpr int PK_MAXL = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const long long* __restrict__ table, int nlayers, long long total) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void pack_dgrad_multi_kernel(const long long* __restrict__ table, int nlayers) {
+    __shared__ long long pre[PK_MAXL + 1];
+    __shared__ T tile[PK_T][PK_T + 2];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        long long acc = 0;
+        for (int l = 0; l < nlayers; ++l) {
+            const long long* e = table + l * 10;
+            const long long taps = e[3] * e[4], tn = (e[6] + PK_T - 1) / PK_T, tc = (e[7] + PK_T - 1) / PK_T;
+            pre[l] = acc;
+            acc += taps * tn * tc;
+        }
+        pre[nlayers] = acc;
+    }
+    __syncthreads();
+    const long long total = pre[nlayers];
+    for (long long tt = blockIdx.x; tt < total; tt += gridDim.x) {
         int lo = 0, hi = nlayers - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (table[mid * 10 + 8] <= i) lo = mid; else hi = mid - 1;
+            if (pre[mid] <= tt) lo = mid; else hi = mid - 1;
         }
         const long long* e = table + lo * 10;
         const T* wf = reinterpret_cast<const T*>(e[0]);
         T* wd = reinterpret_cast<T*>(e[1]);
-        const int N = (int)e[2], KH = (int)e[3], KW = (int)e[4], Cin = (int)e[5], Crun = (int)e[6];
-        const long long j = i - e[8];
-        const long long Kd = (long long)KH * KW * Crun, Kf = (long long)KH * KW * Cin;
-        const int c = (int)(j / Kd);
-        const int r = (int)(j - (long long)c * Kd);
-        const int tap = r / Crun, n = r - tap * Crun;
+        const int N = (int)e[2], KH = (int)e[3], KW = (int)e[4], Cin = (int)e[5], Crun = (int)e[6], rows_d = (int)e[7];
+        const int tn = (Crun + PK_T - 1) / PK_T, tc = (rows_d + PK_T - 1) / PK_T;
+        long long j = tt - pre[lo];
+        const int ci = (int)(j % tc); j /= tc;
+        const int ni = (int)(j % tn);
+        const int tap = (int)(j / tn);                        // destination tap (khd, kwd)
         const int khd = tap / KW, kwd = tap - khd * KW;
-        T v = T(0);
-        if (c < Cin && n < N) v = wf[(long long)n * Kf + ((long long)(KH - 1 - khd) * KW + (KW - 1 - kwd)) * Cin + c];
-        wd[j] = v;
+        const int tapf = (KH - 1 - khd) * KW + (KW - 1 - kwd);
+        const long long Kd = (long long)KH * KW * Crun, Kf = (long long)KH * KW * Cin;
+        const int n0 = ni * PK_T, c0 = ci * PK_T;
+        const int col = t & 63, r4 = t >> 6;
+#pragma unroll 4
+        for (int i = 0; i < PK_T / 4; ++i) {                  // rows = filters n, columns = channels c (contiguous in the source)
+            const int n = n0 + i * 4 + r4, c = c0 + col;
+            T v = T(0);
+            if (n < N && c < Cin) v = wf[(long long)n * Kf + (long long)tapf * Cin + c];
+            tile[i * 4 + r4][col] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < PK_T / 4; ++i) {                  // rows = channels c, columns = filters n (contiguous in the destination)
+            const int c = c0 + i * 4 + r4, n = n0 + col;
+            if (c < rows_d && n < Crun) wd[(long long)c * Kd + (long long)tap * Crun + n] = tile[col][i * 4 + r4];
+        }
+        __syncthreads();
     }
 }
 }  // namespace
@@ -1871,12 +1906,15 @@ extern "C" int rtn_pack_dgrad_weights_multi(rtn_handle_t h, const int64_t* table
     if (!h) return RTN_EINVAL;
     if (!table_dev || nlayers < 1 || total_elems < 1) return rtn_fail(h, RTN_EINVAL, "pack_dgrad_multi: bad argument");
     if (dtype != RTN_BF16 && dtype != RTN_F32) return rtn_fail(h, RTN_EINVAL, "pack_dgrad_multi: bad dtype");
-    long long g = (total_elems + 255) / 256;
-    if (g > 8192) g = 8192;
+    if (nlayers > PK_MAXL) return rtn_fail(h, RTN_EINVAL, "pack_dgrad_multi: at most %d layers per call", PK_MAXL);
+    long long g = (total_elems + PK_T * PK_T - 1) / (PK_T * PK_T);      // about one 64 x 64 tile per workgroup, at most 8 per CU
+    const long long cap = 8ll * (h->num_cus > 0 ? h->num_cus : 256);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
     if (dtype == RTN_BF16)
-        hipLaunchKernelGGL((pack_dgrad_multi_kernel<unsigned short>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers, (long long)total_elems);
+        hipLaunchKernelGGL((pack_dgrad_multi_kernel<unsigned short>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers);
     else
-        hipLaunchKernelGGL((pack_dgrad_multi_kernel<float>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers, (long long)total_elems);
+        hipLaunchKernelGGL((pack_dgrad_multi_kernel<float>), dim3((unsigned)g), dim3(256), 0, h->stream, (const long long*)table_dev, nlayers);
     RTN_CHECK_LAUNCH(h, "pack_dgrad_multi_kernel");
     return RTN_OK;
 }
