@@ -56,6 +56,10 @@ struct G8Params {
     int Hout, Wout;
     float inv_cells, inv_w;
     int relu, out_ld, res_ld, mask_ld, mask_pre;
+    // out_step > 1 (data gradient of a stride-2 1x1 'valid' convolution): row m = (b, oy, ox) of the GEMM is pixel
+    // b * out_img_pix + oy * out_step * out_pix_w + ox * out_step of `out`, `res` and `mask` (all three live on the forward INPUT grid)
+    int out_step, out_pix_w;
+    unsigned out_img_pix;
     // RTN_CONV_RES_UPSAMPLE (EPI bit 0 with res_up): the residual is the coarser pyramid level, read at
     // (min(floor(oy * rs_h), Hres - 1), min(floor(ox * rs_w), Wres - 1)) — UpsampleLike + Add of the FPN laterals (model/layers.py:89-98)
     int res_up, Hres, Wres;
@@ -327,6 +331,13 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 (void*)((EPI & 2) ? p.mask : p.out), 0, (int)__builtin_amdgcn_readfirstlane((int)((EPI & 2) ? p.mask_bytes : 0u)), 0x00020000);
             const int ncol = n0 + wn * (16 * NW) + NW * lrow;
             const bool col_ok = ncol < p.N;
+            auto scatter_pix = [&](int m) -> unsigned {        // pixel of GEMM row m in out / res / mask
+                if (p.out_step <= 1) return (unsigned)m;
+                int b, rem, oy, ox;
+                divmod24(m, p.Hout * p.Wout, p.inv_cells, b, rem);
+                divmod24(rem, p.Wout, p.inv_w, oy, ox);
+                return (unsigned)b * p.out_img_pix + (unsigned)(oy * p.out_step) * (unsigned)p.out_pix_w + (unsigned)(ox * p.out_step);
+            };
             // residual / mask rows of every row fragment: all MI x 4 loads of a wave go out before the first is used (these layers are
             // bound by their pixel traffic: more loads in flight per wave).  NW = 4: 8 bytes per lane and row instead of 16.
             constexpr int NWD = NW / 2;                       // dwords per lane and row
@@ -337,8 +348,9 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * (16 * MI) + i * 16 + kq * 4 + r;
                     const bool ok = col_ok && m < p.M;
+                    const unsigned pm = scatter_pix(ok ? m : 0);
                     if (EPI & 1) {
-                        unsigned rrow = (unsigned)m * (unsigned)p.res_ld;
+                        unsigned rrow = pm * (unsigned)p.res_ld;
                         if (p.res_up) {
                             int b, rem, oy, ox;
                             divmod24(ok ? m : 0, p.Hout * p.Wout, p.inv_cells, b, rem);
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                         else { const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, roff, 0, 0); rq[par][r] = (u32x4){t2.x, t2.y, 0u, 0u}; }
                     }
                     if (EPI & 2) {
-                        const int moff = (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB);
+                        const int moff = (int)(ok ? (pm * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : G8_OOB);
                         if (NW == 8) mq[parm][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, moff, 0, 0);
                         else { const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc, moff, 0, 0); mq[parm][r] = (u32x4){t2.x, t2.y, 0u, 0u}; }
                     }
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
 #pragma unroll
                         for (int j = 0; j < NW; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                     }
-                    const unsigned off = (col_ok && m < p.M) ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)ncol) * 2u : G8_OOB;
+                    const unsigned off = (col_ok && m < p.M) ? (scatter_pix(m < p.M ? m : 0) * (unsigned)p.out_ld + (unsigned)ncol) * 2u : G8_OOB;
                     if constexpr (NW == 8) {
                         u32x4 o;
                         o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
@@ -436,13 +448,23 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (!g.in || !g.out || ((uintptr_t)g.in & 15) || ((uintptr_t)g.out & 15)) return 1;
     const long long cells = (long long)g.Hout * g.Wout, M = cells * d->batch;
     if (M < 1 || M >= (1ll << 24)) return 1;
-    if (g.out_step > 1 || g.out_off != 0 || g.out_img_stride != cells * d->out_ld) return 1;
+    const bool scatter = g.out_step > 1;                  // dgrad of a stride-2 1x1 'valid' conv: rows land on the stride grid
+    if (scatter && (res_up || g.out_pix_w < (g.Wout - 1) * g.out_step + 1 || g.out_img_stride % d->out_ld || g.out_img_stride <= 0)) return 1;
+    const long long img_pix = scatter ? g.out_img_stride / d->out_ld : cells;            // pixels per image of out / res / mask
+    const long long last_pix = scatter ? (long long)(g.Hout - 1) * g.out_step * g.out_pix_w + (long long)(g.Wout - 1) * g.out_step : cells - 1;
+    if (scatter && last_pix >= img_pix) return 1;
+    // measured (tools/profile_train.py, batch 8): the scatter pays on the long-K gradients (res3a / res5a branch1: 0.096 -> 0.077,
+    // 0.071 -> 0.063 ms) and loses on the short-K ones (res3a / res4a branch2a, K = 128 / 256: 0.061 -> 0.076, 0.037 -> 0.049 against
+    // generation 2's 64-wide tiles): taken from K = 512 on
+    if (scatter && !forced && d->Crun < 512) return 1;
+    if (g.out_off != 0 || (!scatter && g.out_img_stride != cells * d->out_ld)) return 1;
     if ((long long)(g.Hout - 1) * d->sy >= g.Hin || (long long)(g.Wout - 1) * d->sx >= g.Win) return 1;
     if (g.in_elems * 2 >= (long long)G8_OOB || g.out_elems * 2 >= (long long)G8_OOB) return 1;
-    if (g.out_elems < (M - 1) * d->out_ld + d->N) return 1;
+    const long long max_pix = (long long)(d->batch - 1) * img_pix + last_pix;             // the farthest pixel a row maps to
+    if (g.out_elems < max_pix * d->out_ld + d->N) return 1;
     if ((epi & 1) && !res_up) {
-        if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride != cells * g.res_ld) return 1;
-        if (g.res_elems < (M - 1) * g.res_ld + d->N || g.res_elems * 2 >= (long long)G8_OOB) return 1;
+        if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride != img_pix * g.res_ld) return 1;
+        if (g.res_elems < max_pix * g.res_ld + d->N || g.res_elems * 2 >= (long long)G8_OOB) return 1;
     }
     if (res_up) {
         if (!g.res || ((uintptr_t)g.res & 15) || g.res_ld % 8 || g.res_img_stride % 8 || g.Hres < 1 || g.Wres < 1) return 1;
@@ -450,8 +472,8 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         if (g.res_elems * 2 >= (long long)G8_OOB) return 1;
     }
     if (epi & 2) {
-        if (!g.mask || ((uintptr_t)g.mask & 15) || g.mask_ld % 8 || g.mask_img_stride != cells * g.mask_ld) return 1;
-        if (g.mask_elems < (M - 1) * g.mask_ld + d->N || g.mask_elems * 2 >= (long long)G8_OOB) return 1;
+        if (!g.mask || ((uintptr_t)g.mask & 15) || g.mask_ld % 8 || g.mask_img_stride != img_pix * g.mask_ld) return 1;
+        if (g.mask_elems < max_pix * g.mask_ld + d->N || g.mask_elems * 2 >= (long long)G8_OOB) return 1;
     }
     const long long in_max = (long long)(d->batch - 1) * g.in_img_stride + (long long)(g.Hout - 1) * d->sy * g.in_row_stride +
                              (long long)(g.Wout - 1) * d->sx * d->pix_stride + d->Crun;
@@ -514,6 +536,7 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (epi & 1) { p.res = (const char*)g.res; p.res_bytes = (unsigned)(g.res_elems * 2); p.res_ld = g.res_ld; }
     if (epi & 2) { p.mask = (const char*)g.mask; p.mask_bytes = (unsigned)(g.mask_elems * 2); p.mask_ld = g.mask_ld; }
     p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
+    p.out_step = scatter ? g.out_step : 1; p.out_pix_w = g.out_pix_w; p.out_img_pix = (unsigned)img_pix;
     if (res_up) {
         p.res_up = 1; p.Hres = g.Hres; p.Wres = g.Wres;
         p.res_img_stride = (unsigned)g.res_img_stride;

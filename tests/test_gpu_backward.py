@@ -625,3 +625,68 @@ def test_wgrad_ring_kernel_equals_the_two_stage_kernel_bit_for_bit(pkg, handle, 
     assert torch.equal(b0, b1)
     want_db = dy.float().cpu().double().sum(dim=(0, 1))
     assert float((b1.double() - want_db).abs().max()) <= 1e-4 * float(want_db.abs().max())
+
+
+@pytest.mark.parametrize("H,W,cin,cout,B,grid,mode", [
+    (33, 51, 256, 512, 3, 0, "res+mask"),      # res3a_branch1 / res4a_branch2a-like: N = 256 gradient channels, K = 512
+    (17, 23, 256, 128, 2, 2, "res+mask_pre"),  # two workgroups, odd extents: the last row / column of the stride grid
+    (40, 66, 128, 256, 2, 3, "res+mask"),      # N = 128: the 128-column instance (8-byte residual / mask accesses) with the scatter
+    (21, 35, 512, 1024, 1, 0, "mask"),         # no accumulated gradient: plain scatter of masked values
+])
+def test_stride2_1x1_dgrad_scatter_on_generation5(pkg, handle, monkeypatch, H, W, cin, cout, B, grid, mode):
+    """The data gradient of a stride-2 1x1 'valid' convolution (the first block of a stage: res3a/4a/5a branch1 and branch2a,
+    keras_resnet bottleneck behind model/defineModel.py:376-380) is a GEMM over dY whose rows land on every second pixel of the
+    input grid (rtn_conv_group_t.out_step = 2).  Generation 5's register epilogue now does that scatter itself - output, accumulated
+    gradient (in place) and ReLU-mask rows are all addressed through the (b, 2 oy, 2 ox) pixel of the row - instead of leaving
+    these layers to generation 2.  Against float64 autograd on the bf16 operands; pixels off the stride grid keep their bits."""
+    L = pkg._lib
+    dtype = "bf16"
+    tdt, code = DT[dtype]
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    g = torch.Generator().manual_seed(700 + grid + cin)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype).requires_grad_(True)
+    w = q(torch.randn(1, 1, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(cin), dtype)
+    y = fwd_ref(x, w, 2, 0, 0, Ho, Wo)
+    dy = q(torch.randn(B, Ho, Wo, cout, generator=g, dtype=torch.float64), dtype)
+    other = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+    act = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+    dx = torch.autograd.grad(y, x, dy)[0]
+    keepm = act > 0
+    if "res" in mode:
+        want = dx * keepm + other if "pre" in mode else (dx + other) * keepm
+    else:
+        want = dx * keepm
+    wk, rows = pack_fwd(w, dtype)
+    wd = torch.zeros(cin, cout, dtype=tdt, device=DEV)
+    handle.check(L.lib.rtn_pack_dgrad_weights(handle.raw, wk.data_ptr(), wd.data_ptr(), code, cout, rows, 1, 1, cin, cout, cin))
+    dyd, actd = dy.to(tdt).to(DEV).contiguous(), act.to(tdt).to(DEV).contiguous()
+    start = other if "res" in mode else torch.full((B, H, W, cin), -77.0, dtype=torch.float64)
+    dxd = start.to(tdt).to(DEV).contiguous()
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = 1, B, code
+    d.w, d.w_rows, d.N, d.KH, d.KW = wd.data_ptr(), cin, cin, 1, 1
+    d.Crun = d.pix_stride = cout
+    d.sy = d.sx = 1
+    d.out_ld = cin
+    d.flags = (L.CONV_RES_SAME if "res" in mode else 0) | L.CONV_RELU_MASK | (L.CONV_MASK_PRE if "pre" in mode else 0)
+    grp = L.ConvGroup()
+    grp.in_, grp.in_elems, grp.in_img_stride, grp.in_row_stride = dyd.data_ptr(), dyd.numel(), Ho * Wo * cout, Wo * cout
+    grp.Hin, grp.Win, grp.Hout, grp.Wout = Ho, Wo, Ho, Wo
+    grp.out_step, grp.out_pix_w = 2, W
+    grp.out, grp.out_elems, grp.out_img_stride = dxd.data_ptr(), dxd.numel(), H * W * cin
+    if "res" in mode:
+        grp.res, grp.res_elems, grp.res_img_stride, grp.res_ld = dxd.data_ptr(), dxd.numel(), H * W * cin, cin
+    grp.mask, grp.mask_elems, grp.mask_img_stride, grp.mask_ld = actd.data_ptr(), actd.numel(), H * W * cin, cin
+    d.g[0] = grp
+    handle.check(L.lib.rtn_conv2d_dgrad(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+    got = dxd.cpu().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got[:, ::2, ::2] - want[:, ::2, ::2]).abs().max())
+    assert err <= tol(dtype) * scale, "scattered dgrad err %.3e scale %.2f" % (err, scale)
+    rest = torch.ones(H, W, dtype=torch.bool)
+    rest[::2, ::2] = False
+    assert torch.equal(got[:, rest], q(start, dtype)[:, rest])            # untouched off the stride grid
