@@ -1307,6 +1307,15 @@ static bool wgrad_takes_halo(const rtn_conv_desc_t* d, const WgradPlan& w) {
     return !w.dma && w.tiles >= 400;
 }
 
+// rtn_wgrad_win.hip (all nine taps per output tile over a sliding window of the input; stride-1 3x3 layers with whole blocks of 128
+// filters and 64 channels).  RTN_WGRAD_WIN=1: wherever the shape allows (tests, A/B), 0: never.
+static bool wgrad_takes_win(const rtn_conv_desc_t* d, const WgradPlan& w) {
+    const int knob = rtn_env_int("RTN_WGRAD_WIN", -1);
+    if (knob == 0 || rtn_wgrad_win_workspace_bytes(d) == 0) return false;
+    if (knob > 0) return true;
+    return false;
+}
+
 // workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel
 // (rtn_wgrad_halo.hip) uses the same bytes for its own slabs
 extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
@@ -1318,7 +1327,9 @@ extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
     if (rtn_env_int("RTN_WGRAD_SLAB", 1) != 0)
         table += (size_t)w.nsplit_used * (size_t)d->N * ((size_t)d->KH * d->KW * d->Crun + 1) * sizeof(float);
     const size_t halo = wgrad_takes_halo(d, w) ? rtn_wgrad_halo_workspace_bytes(d) : 0;
-    return table > halo ? table : halo;
+    const size_t win = wgrad_takes_win(d, w) ? rtn_wgrad_win_workspace_bytes(d) : 0;
+    const size_t special = halo > win ? halo : win;
+    return table > special ? table : special;
 }
 
 static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes,
@@ -1370,8 +1381,9 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         if (workspace_bytes < need) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, need);
     }
 
+    const bool take_win = wgrad_takes_win(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256));
     // the stride-1 3x3 layers with whole 128-channel blocks that rtn_wgrad_halo.hip runs faster (wgrad_takes_halo)
-    if (wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
+    if (take_win || wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
         bool ok = true;
         for (int i = 0; i < d->ngroups && ok; ++i) {
             const rtn_conv_group_t& s = d->g[i];
@@ -1381,9 +1393,16 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         }
         if (ok) {
             if (mode == 1) return RTN_OK;              // nothing to prepare
-            const int rc = rtn_wgrad_halo_try(h, d, dW, db, db_n, workspace, workspace_bytes);
-            if (rc == RTN_OK) h->last_wgrad_impl = 1;
-            if (rc <= 0) return rc;
+            if (take_win) {
+                const int rc = rtn_wgrad_win_try(h, d, dW, db, db_n, workspace, workspace_bytes);
+                if (rc == RTN_OK) h->last_wgrad_impl = 4;
+                if (rc <= 0) return rc;
+            }
+            if (wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
+                const int rc = rtn_wgrad_halo_try(h, d, dW, db, db_n, workspace, workspace_bytes);
+                if (rc == RTN_OK) h->last_wgrad_impl = 1;
+                if (rc <= 0) return rc;
+            }
         }
     }
 

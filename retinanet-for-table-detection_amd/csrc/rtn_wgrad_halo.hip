@@ -267,13 +267,16 @@ __global__ __launch_bounds__(WH_THREADS, 2) void conv_wgrad_halo_kernel(const WH
 // over enough threads.  Blocks past `main_blocks` do the same for the bias slabs (scalar columns).
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dW, const float* __restrict__ slab, int S, long long NK,
-                                                           float* __restrict__ db, const float* __restrict__ bslab, int N, int db_n, int main_blocks) {
+                                                           float* __restrict__ db, const float* __restrict__ bslab, int N, int db_n, int main_blocks,
+                                                           int bS, rtn_wgrad_frag_t fr) {
     constexpr int CB = 256 / SL;
     __shared__ float4 part[SL][CB];
     const int c = threadIdx.x % CB, sl = threadIdx.x / CB;
-    const int per = (S + SL - 1) / SL;
-    const int s0 = sl * per, s1 = s0 + per < S ? s0 + per : S;
-    if ((int)blockIdx.x < main_blocks) {
+    const bool is_main = (int)blockIdx.x < main_blocks;
+    const int Sx = is_main ? S : bS;                      // the bias slabs may come in a different number of parts (rtn_wgrad_win.hip)
+    const int per = (Sx + SL - 1) / SL;
+    const int s0 = sl * per < Sx ? sl * per : Sx, s1 = s0 + per < Sx ? s0 + per : Sx;
+    if (is_main) {
         const long long i = (long long)blockIdx.x * CB + c;          // float4 column
         const bool live = i < NK / 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -287,9 +290,25 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ d
         if (sl == 0 && live) {
 #pragma unroll
             for (int l = 1; l < SL; ++l) { const float4 a = part[l][c]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-            float4 w = reinterpret_cast<float4*>(dW)[i];
-            w.x += v.x; w.y += v.y; w.z += v.z; w.w += v.w;
-            reinterpret_cast<float4*>(dW)[i] = w;
+            if (fr.ncb > 0) {
+                // slabs in accumulator-fragment order (rtn_wgrad_win.hip): float4 i = [tile][wave][tap j][i4][lane] holds rows
+                // n .. n + 3 of ONE column: n = 128 tn + 64 wm + 16 i4 + 4 (lane / 16), k = j C + 64 cb + 16 wk + lane % 16
+                const int lane = (int)(i & 63);
+                const unsigned f = (unsigned)(i >> 6);                  // NK < 2^32
+                const int i4 = (int)(f & 3);
+                const unsigned t2 = f >> 2, t3 = t2 / 9u;
+                const int j = (int)(t2 - t3 * 9u);
+                const int wave = (int)(t3 & 7), tile = (int)(t3 >> 3);
+                const int tn = tile / fr.ncb, cb = tile - tn * fr.ncb;
+                const int n = 128 * tn + 64 * (wave >> 2) + 16 * i4 + 4 * (lane >> 4);
+                const int k = j * fr.C + 64 * cb + 16 * (wave & 3) + (lane & 15);
+                float* o = dW + (size_t)n * fr.Ktot + k;
+                o[0] += v.x; o[fr.Ktot] += v.y; o[2 * (size_t)fr.Ktot] += v.z; o[3 * (size_t)fr.Ktot] += v.w;
+            } else {
+                float4 w = reinterpret_cast<float4*>(dW)[i];
+                w.x += v.x; w.y += v.y; w.z += v.z; w.w += v.w;
+                reinterpret_cast<float4*>(dW)[i] = w;
+            }
         }
     } else {
         const int n = ((int)blockIdx.x - main_blocks) * CB + c;
@@ -347,14 +366,18 @@ bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
 
 // dW[0..NK) += slab[0] + slab[1] + ... + slab[S-1] (in that order), db[0..db_n) likewise from bslab[S][N]: the ordered reduction
 // of the pixel splits of every weight-gradient kernel
-int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n) {
+int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n, int bS,
+                     const rtn_wgrad_frag_t* frag) {
     if (!dW || !slab || S < 1 || NK < 4 || NK % 4) return rtn_fail(h, RTN_EINVAL, "wgrad finish: bad argument");
     const int nb = db ? db_n : 0;
+    if (bS < 1) bS = S;
+    rtn_wgrad_frag_t fr = {0, 0, 0};
+    if (frag) fr = *frag;
 #define RTN_WF(SL_)                                                                                               \
     do {                                                                                                          \
         const long long mb = (NK / 4 + 256 / SL_ - 1) / (256 / SL_);                                              \
         const long long bb = (nb + 256 / SL_ - 1) / (256 / SL_);                                                  \
-        hipLaunchKernelGGL((wgrad_finish_kernel<SL_>), dim3((unsigned)(mb + bb)), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, nb, (int)mb); \
+        hipLaunchKernelGGL((wgrad_finish_kernel<SL_>), dim3((unsigned)(mb + bb)), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, nb, (int)mb, bS, fr); \
     } while (0)
     if (S >= 64) RTN_WF(16); else if (S >= 8) RTN_WF(4); else RTN_WF(1);
 #undef RTN_WF

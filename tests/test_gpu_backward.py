@@ -306,6 +306,79 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
     assert float((db0 - db1).abs().max()) <= 1e-3 * max(1.0, float(wantb.abs().max()))
 
 
+@pytest.mark.parametrize("levels,cin,cout,B,bias", [
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 4, True),     # head tower: five levels, runs change level inside a split
+    ([(100, 167)], 256, 256, 1, True),         # P3 at 800 x 1333: the widest window (D = 6), 32 splits
+    ([(25, 42)], 256, 256, 2, False),          # P5 / res4 branch2b-like, no bias
+    ([(40, 67)], 128, 128, 3, True),           # res3 branch2b: 2 output tiles, 128 splits asked for
+    ([(13, 21)], 512, 512, 3, False),          # res5 branch2b: 32 output tiles, 8 splits
+    ([(7, 300)], 64, 128, 1, True),            # image rows of 300 pixels: D = 10; one channel tile
+    ([(3, 5), (64, 64)], 128, 256, 2, True),   # a tiny level first: its stages end inside the first split
+])
+def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bias):
+    """csrc/rtn_wgrad_win.hip: weight (+ bias) gradient of the stride-1 3x3 layers with all nine taps in one output tile over a
+    sliding window of the input.  Against float64 autograd on the bf16-rounded operands, against the general kernels
+    (RTN_WGRAD_WIN=0, RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (ordered slab sums)."""
+    L = pkg._lib
+    dtype = "bf16"
+    tdt, code = DT[dtype]
+    g = torch.Generator().manual_seed(900 + cin + cout)
+    w = q(torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(9 * cin), dtype).requires_grad_(True)
+    d = L.ConvDesc()
+    d.ngroups, d.batch, d.dtype = len(levels), B, code
+    d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
+    d.Crun = d.pix_stride = cin
+    d.sy = d.sx = 1
+    d.pad_t = d.pad_l = 1
+    d.out_ld = cout
+    keep, want, wantb = [], 0, 0
+    for gi, (H, W) in enumerate(levels):
+        x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
+        dy = q(torch.randn(B, H, W, cout, generator=g, dtype=torch.float64), dtype)
+        y = fwd_ref(x, w, 1, 1, 1, H, W)
+        want = want + torch.autograd.grad(y, w, dy)[0]
+        wantb = wantb + dy.sum(dim=(0, 1, 2))
+        xd, dyd = x.to(tdt).to(DEV).contiguous(), dy.to(tdt).to(DEV).contiguous()
+        keep += [xd, dyd]
+        grp = L.ConvGroup()
+        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
+        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems, grp.out_img_stride = dyd.data_ptr(), dyd.numel(), H * W * cout
+        d.g[gi] = grp
+    wantm = want.permute(3, 0, 1, 2).reshape(cout, -1)
+
+    def run(win):
+        monkeypatch.setenv("RTN_WGRAD_WIN", "1" if win else "0")
+        monkeypatch.setenv("RTN_WGRAD_HALO", "0")
+        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        dW = torch.full((cout, 9 * cin), 0.5, dtype=torch.float32, device=DEV)
+        db = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
+        if bias:
+            handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        else:
+            handle.check(L.lib.rtn_conv2d_wgrad(handle.raw, C.byref(d), dW.data_ptr(), ws.data_ptr(), wsb))
+        torch.cuda.synchronize()
+        assert (L.lib.rtn_debug_last_wgrad_impl(handle.raw) == 4) == win       # 0 / 2 / 3: the general kernels
+        return dW.cpu(), db.cpu()
+
+    dW1, db1 = run(True)
+    scale = max(1.0, float(wantm.abs().max()))
+    err = float((dW1.double() - 0.5 - wantm).abs().max())
+    assert err <= tol(dtype) * scale, "wgrad err %.3e scale %.2f" % (err, scale)
+    if bias:
+        errb = float((db1.double() - 0.25 - wantb).abs().max())
+        assert errb <= tol(dtype) * max(1.0, float(wantb.abs().max())), "bias grad err %.3e" % errb
+    else:
+        assert float((db1 - 0.25).abs().max()) == 0.0
+    dW2, db2 = run(True)
+    assert torch.equal(dW1, dW2) and torch.equal(db1, db2)                 # ordered sums: the same bits every time
+    dW0, db0 = run(False)                                                   # the general kernel: same values, other order
+    assert float((dW0 - dW1).abs().max()) <= 1e-3 * scale
+    assert float((db0 - db1).abs().max()) <= 1e-3 * max(1.0, float(wantb.abs().max())) if bias else True
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("H,W,cin,cout,k,B,env", [
     (40, 67, 256, 64, 1, 4, {}),                           # 128 x 128 kernel, many pixel splits (XCD map)
