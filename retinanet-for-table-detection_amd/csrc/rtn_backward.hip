@@ -1308,12 +1308,16 @@ static bool wgrad_takes_halo(const rtn_conv_desc_t* d, const WgradPlan& w) {
 }
 
 // rtn_wgrad_win.hip (all nine taps per output tile over a sliding window of the input; stride-1 3x3 layers with whole blocks of 128
-// filters and 64 channels).  RTN_WGRAD_WIN=1: wherever the shape allows (tests, A/B), 0: never.
+// filters and 64 channels, image rows of up to 254 pixels) against the kernels above, measured per shape at batch 8 (tools/ab_wgrad.py,
+// profiles/r3_wgrad_win_ab.txt): head towers 0.197 vs 0.285 ms, P3 0.157 vs 0.216, res4 branch2b / P4 0.068 vs 0.076, res3 branch2b
+// 0.065 vs 0.068, res5 branch2b 0.071 vs 0.087, but P5 (8,400 pixels x 8 output tiles = 64 workgroups) 0.048 vs 0.042: it takes the
+// layers with enough work for a chip-wide grid, 64-pixel tiles x output tiles >= 3000 (res5 4,192, res4 4,200, P5 1,048).
+// RTN_WGRAD_WIN=1: wherever the shape allows (tests, A/B), 0: never.
 static bool wgrad_takes_win(const rtn_conv_desc_t* d, const WgradPlan& w) {
     const int knob = rtn_env_int("RTN_WGRAD_WIN", -1);
     if (knob == 0 || rtn_wgrad_win_workspace_bytes(d) == 0) return false;
     if (knob > 0) return true;
-    return false;
+    return w.tiles * (long long)(d->N / 128) * (d->Crun / 64) >= 3000;
 }
 
 // workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel

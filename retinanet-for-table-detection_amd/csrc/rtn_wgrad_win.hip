@@ -5,26 +5,32 @@
 //     dW[n][(kh, kw, c)] += sum over pixels m of  dY[m][n] * X[m + (kh - 1) * W + (kw - 1)][c]
 //
 // The per-tap kernels (rtn_backward.hip: 256 x 256 tile per tap; rtn_wgrad_halo.hip: one kernel row per tile) stage 7.6 / 5.3 KB of
-// operands per MFLOP and all run into the same ~25 GB/s per CU of operand staging.  Here a workgroup owns
-// 128 filters x 64 channels x 9 taps (288 KB of f32 accumulators = 144 registers per lane in 8 waves) and walks the pixels ONCE:
+// operands per MFLOP and read 0.75 / 0.83 transposed fragments per MFMA.  Here a workgroup owns 128 filters x 64 channels x 9 taps
+// (288 KB of f32 accumulators = 144 registers per lane in 8 waves) and walks the pixels ONCE:
 //   * the pixel stream of a level is PADDED with one non-existent pixel after every image row and one non-existent row after every
 //     image (they stage as zeros), so that tap (kh, kw) of padded slot u is slot u + (kh - 1) * (W + 1) + (kw - 1) with no test at all;
-//   * X lives in a RING of 896 slots (128 B = 64 channels each): one step = 32 slots; the step multiplies the 32 dY rows that arrived
-//     with it against nine shifted 32-row views of the ring, which then holds the slots from one image row above to one below
-//     (2 D + 1 blocks of 32, D = ceil((W + 2) / 32)).  Every X row is staged ONCE per workgroup (plus 2 D blocks of run-in per pixel
-//     split): 384 B per slot for 147 KFLOP = 2.6 KB per MFLOP;
-//   * LDS-DMA three steps ahead (dY: 4 stages of 32 x 256 B; X: the ring itself), one counted s_waitcnt and one barrier per step,
-//     36 MFMAs (16x16x32 bf16) per wave and step against 13 transposed fragment reads: the 4 dY^T fragments are shared by the 9 taps;
+//   * X lives in a RING of blocks of 64 slots (128 B = 64 channels per slot): one step = 64 slots; the step multiplies the 64 dY rows
+//     that arrived with it against nine shifted 64-row views of the ring, which holds the slots from one image row above to one
+//     below (2 D + 1 blocks, D = ceil((W + 2) / 64)).  Every X row is staged ONCE per workgroup (plus 2 D blocks of run-in per pixel
+//     split): 384 B per slot for 147 KFLOP = 2.6 KB per MFLOP, and 13 fragment reads per 36 MFMAs (the 4 dY^T fragments of a
+//     32-slot half step are shared by the 9 taps);
+//   * LDS-DMA two steps ahead (dY: 3 stages of 64 x 256 B; X: the ring itself), one counted s_waitcnt and ONE barrier per step =
+//     72 MFMAs (16x16x32 bf16) per wave; the two waves of a SIMD issue their three LDS-DMA pieces at different points of the step
+//     (waves 0-3 behind the barrier, waves 4-7 between the half steps), so one of them keeps the matrix core fed meanwhile;
 //   * fragments are read transposed (ds_read_b64_tr_b16: the reduction index, pixels, is the row index in memory); conflict-free
 //     through an XOR of the 32-byte granule with key(row) = (row & 3) | ((row >> 3) & 1) << 2 on the 256-byte dY rows and
 //     key(row) = ((row >> 1) & 1) | ((row >> 3) & 1) << 1 on the 128-byte X rows — both depend on row mod 16 only, so a view shifted by
-//     any number of slots stays conflict-free;
+//     any number of slots stays conflict-free.  Ring addresses wrap once per step and tap (add, subtract, min); the second row of
+//     a fragment (+ 4 slots) and the second half step (+ 32 slots) use fixed distances from it, reading up to 4.6 KB past the ring's
+//     end: ring block 0 is staged a second time behind the ring (the mirror);
 //   * the level changes inside a pixel split without draining the pipeline: the steps of a split are a list of runs (level, first
 //     block, last block), the first 2 D steps of a run only load;
 //   * pixel splits x output tiles are laid out so that all tiles of a split run on ONE XCD (they read the same pixels: one L2);
-//   * no atomics: slab[split][n][k] + rtn_wgrad_finish (fixed order), the bias gradient as one extra MFMA against a ones fragment
-//     that the 4 channel tiles x 4 waves sharing a dY fragment take in turns.
-// LDS: 112 KiB (X ring) + 32 KiB (dY) = 144 KiB, one workgroup of 8 waves = 2 (filter halves of 64) x 4 (channel slices of 16) per CU.
+//   * no atomics: every (split, tile) stores its accumulator fragments as they lie in the registers (16 B per lane, 1 KiB per store)
+//     and rtn_wgrad_finish adds the splits in a fixed order and puts them in place; the bias gradient is one extra MFMA against a
+//     ones fragment that the channel tiles x 4 waves sharing a dY fragment take in turns.
+// LDS: X ring (2 D + 4 blocks of 8 KiB) + mirror 8 KiB + dY 48 KiB = 136 KiB for rows of up to 190 pixels (D = 3), 152 KiB up to 254.
+// One workgroup of 8 waves = 2 (filter halves of 64) x 4 (channel slices of 16) per CU.
 #include "rtn_internal.h"
 #include <type_traits>
 
@@ -38,36 +44,35 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 constexpr unsigned WW_OOB = 0xFFFFFF00u;
 constexpr int WW_THREADS = 512;
-constexpr int WW_SP = 32;                              // pixel slots per step
-constexpr unsigned WW_XBLK = WW_SP * 128;              // one X block: 32 slots x 64 channels = 4 KiB
-constexpr unsigned WW_MIRROR = 2 * WW_XBLK;            // blocks 0 and 1 once more behind the ring: reads may run 4 KiB + 576 B past its end
-constexpr unsigned WW_DYST = WW_SP * 256;              // one dY stage: 32 slots x 128 filters = 8 KiB
+constexpr int WW_SP = 64;                              // pixel slots per step
+constexpr unsigned WW_XBLK = WW_SP * 128;              // one X block: 64 slots x 64 channels = 8 KiB
+constexpr unsigned WW_MIRROR = WW_XBLK;                // ring block 0 once more behind the ring
+constexpr unsigned WW_DYST = WW_SP * 256;              // one dY stage: 64 slots x 128 filters = 16 KiB
+constexpr int WW_LA = 2;                               // steps a load runs ahead of its use
+constexpr int WW_NDY = WW_LA + 1;
 constexpr int WW_LDS_MAX = 160 * 1024;
-// LDS of a launch: X ring of nblk blocks (even; >= 2 Dmax + 1 + LA + 1) | mirror | LA + 1 dY stages | 4 KiB nobody reads (where waves
-// 4-7 point their second piece when the block has no mirror).  LA = steps a load runs ahead of its use: the staging rate of a CU is
-// (bytes in flight) / (memory latency), 12 KiB per step against ~1.7 us (measured: 21 GB/s per CU with LA = 3).
-constexpr int ww_lds_bytes(int nblk, int la) { return (int)(nblk * WW_XBLK + WW_MIRROR + (la + 1) * WW_DYST + WW_XBLK); }
+constexpr int ww_nblk(int D) { return 2 * D + 1 + WW_LA + 1; }
+constexpr int ww_lds_bytes(int D) { return (int)(ww_nblk(D) * WW_XBLK + WW_MIRROR + WW_NDY * WW_DYST); }
 
 struct WWSeg {
     const char* x;
     const char* dy;
     unsigned x_bytes, dy_bytes;
     int H, W, Mp;                            // Mp: slots of the padded stream, batch * (H + 1) * (W + 1)
-    int stage_begin, nst, D;                 // first output stage (32 slots) of the level in the launch, their number, ceil((W + 2) / 32)
+    int stage_begin, nst, D;                 // first output stage (64 slots) of the level in the launch, their number, ceil((W + 2) / 64)
     unsigned cells_p, mg_cells, sh_cells;    // (H + 1) * (W + 1) and the multiply-shift pair dividing by it (exact below 2^24)
     unsigned mg_w1, sh_w1;                   // ... by W + 1
 };
 
 struct WWParams {
     WWSeg g[RTN_MAX_GROUPS];
-    float* slab;                  // [S][N][9 C]
+    float* slab;                  // [S][tile][wave][tap][4][64 lanes][4]: accumulator fragments
     float* bslab;                 // [S * ncb][N] partial column sums of dY (fused BiasAddGrad) or null
     int ngroups, total_stages, stages_per_split, S;
     int ntiles, ncb;              // output tiles = (N / 128) x ncb channel blocks of 64
     int N, C, Ktot;
     int pix_b, dy_ld_b;
-    unsigned xring;               // bytes of the X ring (nblk blocks)
-    int dbg;                      // RTN_WGRAD_WIN_DBG (timing ablations, wrong results): 1 = no staging in the loop, 2 = no fragment reads / MFMAs
+    unsigned xring;               // bytes of the X ring
 };
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
@@ -89,20 +94,7 @@ __device__ __forceinline__ void dma16(const i32x4& srd, unsigned voff, unsigned 
                  : "memory");
 }
 
-__device__ __forceinline__ s16x8 read_tr(const char* lds0, unsigned off_lo, unsigned off_hi) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds0 + off_lo));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds0 + off_hi));
-    return (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-// One cursor over the steps of a pixel split: run = the part of a level inside the split's range of output stages [glo, ghi);
-// its steps are the X blocks k = s_lo .. s_hi - 1 + 2 D (block k = padded slots 32 (k - D) .. + 31), step k multiplies output stage
-// k - 2 D when that is >= s_lo (the first 2 D steps of a run only fill the ring).  Runs have an EVEN number of steps (one more
-// load-only step in front when needed): the multiply loop goes in pairs of steps and a pair never straddles two levels.
-struct Cursor {
-    int g, k, k_end, s_lo, D, done;
-};
-
+// transposed fragment: 4 + 4 reduction rows x 16 columns; the addresses are LDS byte offsets (the kernel's dynamic LDS starts at 0)
 __device__ __forceinline__ s16x8 read_tr_at(unsigned lo, unsigned hi) {
     typedef __attribute__((address_space(3))) s16x4* lds_p;
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(__UINTPTR_TYPE__)lo);
@@ -110,11 +102,18 @@ __device__ __forceinline__ s16x8 read_tr_at(unsigned lo, unsigned hi) {
     return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int ISSUE_AT, int WW_LA, int EXP = 0>
+// One cursor over the steps of a pixel split: run = the part of a level inside the split's range of output stages [glo, ghi);
+// its steps are the X blocks k = s_lo .. s_hi - 1 + 2 D (block k = padded slots 64 (k - D) .. + 63), step k multiplies output stage
+// k - 2 D when that is >= s_lo (the first 2 D steps of a run only fill the ring).
+struct Cursor {
+    int g, k, k_end, s_lo, D, done;
+};
+
+// EXP (timing experiments, wrong results): 1 = no staging in the loop, 2 = no fragment reads / MFMAs, 3 = neither
+template <int EXP>
 __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int WW_NDY = WW_LA + 1;
-    const unsigned WW_XRING = p.xring, WW_DY_BASE = WW_XRING + WW_MIRROR, WW_DUMMY = WW_DY_BASE + WW_NDY * WW_DYST;
+    const unsigned XRING = p.xring, DY_BASE = XRING + WW_MIRROR;
     // workgroup -> (output tile, pixel split): the tiles of one split sit on one XCD
     const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
     const int sl = jx / p.ntiles, tile = jx - sl * p.ntiles, split = sl * 8 + xcd;
@@ -138,31 +137,22 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
             const int b = p.g[g].stage_begin, n = p.g[g].nst;
             const int lo = glo > b ? glo : b, hi = ghi < b + n ? ghi : b + n;
             if (lo < hi) {
-                c.g = g; c.s_lo = lo - b; c.D = p.g[g].D; c.k_end = hi - b + 2 * c.D; c.done = 0;
-                c.k = c.s_lo - ((c.k_end - c.s_lo) & 1);
+                c.g = g; c.s_lo = lo - b; c.k = c.s_lo; c.D = p.g[g].D; c.k_end = hi - b + 2 * c.D; c.done = 0;
                 break;
             }
         }
     };
-    int T = 0;                                         // steps of this split (even)
-    {
-        Cursor c;
-        next_run(c, 0);
-        while (!c.done) { T += c.k_end - c.k; next_run(c, c.g + 1); }
-        if (p.dbg & 4) T = 0;
-    }
 
-    // ---- staging role.  dY: every wave one piece (4 rows of 256 B): row 4 wave + lane / 16, LDS chunk position lane % 16.
-    // X: waves 0-3 one piece (8 rows of 128 B): row 8 wave + lane / 8, chunk position lane % 8; waves 4-7 write the same piece once
-    // more into the mirror behind the ring when the block is ring block 0 or 1 (else an out-of-range piece into a dummy area: every
-    // wave issues two pieces per step, one counted wait for all).
+    // ---- staging role: three pieces per wave and step.  dY: rows 4 wave + lane / 16 and that + 32 (4 rows of 256 B per piece),
+    // LDS chunk position lane % 16.  X: rows 8 wave + lane / 8 (8 rows of 128 B), chunk position lane % 8; a fourth piece writes the
+    // X rows once more behind the ring when the block is ring block 0.
     const int dy_row = 4 * wave + (lane >> 4);
     unsigned dy_col;
     {
         const int key = (dy_row & 3) | (((dy_row >> 3) & 1) << 2), cpos = lane & 15;
         dy_col = (unsigned)((n0 + ((((cpos >> 1) ^ key) << 1) | (cpos & 1)) * 8) * 2);
     }
-    const int x_row = 8 * (wave & 3) + (lane >> 3);
+    const int x_row = 8 * wave + (lane >> 3);
     unsigned x_col;
     {
         const int key = ((x_row >> 1) & 1) | (((x_row >> 3) & 1) << 1), cpos = lane & 7;
@@ -193,21 +183,16 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     };
     auto issue_step = [&]() {
         const bool live = !lc.done;
-        {
-            const int s = lc.k - 2 * lc.D;
-            const unsigned v = slot_offset(s * WW_SP + dy_row, live && s >= lc.s_lo, (unsigned)p.dy_ld_b, dy_col);
-            dma16(ys, v, WW_DY_BASE + dyl_ring + (unsigned)wave * 1024u);
-        }
-        if (wave < 4) {
-            const unsigned v = slot_offset((lc.k - lc.D) * WW_SP + x_row, live, (unsigned)p.pix_b, x_col);
-            dma16(xs, v, xl_ring + (unsigned)wave * 1024u);
-        } else if (xl_ring < WW_MIRROR) {
-            const unsigned v = slot_offset((lc.k - lc.D) * WW_SP + x_row, live, (unsigned)p.pix_b, x_col);
-            dma16(xs, v, WW_XRING + xl_ring + (unsigned)(wave & 3) * 1024u);
-        } else {
-            dma16(xs, WW_OOB, WW_DUMMY + (unsigned)(wave & 3) * 1024u);
-        }
-        xl_ring = xl_ring == WW_XRING - WW_XBLK ? 0u : xl_ring + WW_XBLK;
+        const int s = lc.k - 2 * lc.D;
+        const bool dy_live = live && s >= lc.s_lo;
+        const unsigned v0 = slot_offset(s * WW_SP + dy_row, dy_live, (unsigned)p.dy_ld_b, dy_col);
+        const unsigned v1 = slot_offset(s * WW_SP + 32 + dy_row, dy_live, (unsigned)p.dy_ld_b, dy_col);
+        const unsigned vx = slot_offset((lc.k - lc.D) * WW_SP + x_row, live, (unsigned)p.pix_b, x_col);
+        dma16(ys, v0, DY_BASE + dyl_ring + (unsigned)wave * 1024u);
+        dma16(ys, v1, DY_BASE + dyl_ring + 8192u + (unsigned)wave * 1024u);
+        dma16(xs, vx, xl_ring + (unsigned)wave * 1024u);
+        if (xl_ring == 0) dma16(xs, vx, XRING + (unsigned)wave * 1024u);
+        xl_ring = xl_ring == XRING - WW_XBLK ? 0u : xl_ring + WW_XBLK;
         dyl_ring = dyl_ring == (WW_NDY - 1) * WW_DYST ? 0u : dyl_ring + WW_DYST;
         if (live && ++lc.k == lc.k_end) {
             next_run(lc, lc.g + 1);
@@ -215,17 +200,18 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
         }
     };
 
-    // ---- fragment roles (transposed reads): lane (g, q, pp) supplies rows 8 g + q and 8 g + q + 4 of the step's 32 slots and 4
-    // channels.  dY^T fragment i = filters n0 + 64 wm + 16 i ..: fixed offsets inside the dY stage (the second row 1 KiB further:
-    // same swizzle key).  X^T fragment of tap (kh, kw): rows shifted by (kh - 1)(W + 1) + (kw - 1) slots, counted from the first
-    // row of the block that arrived with this step; the second row sits 512 B further, +- 64 B where the shift carries into row bit 3.
+    // ---- fragment roles (transposed reads): lane (g, q, pp) supplies rows 8 g + q and 8 g + q + 4 of a 32-slot half step and 4
+    // channels.  dY^T fragment i = filters n0 + 64 wm + 16 i ..: fixed offsets inside the dY stage (second row + 1 KiB: same swizzle
+    // key; second half step + 8 KiB).  X^T fragment of tap (kh, kw): rows shifted by (kh - 1)(W + 1) + (kw - 1) slots, counted from
+    // the first row of the block that arrived with this step; the second row sits 512 B further, +- 64 B where the shift carries into
+    // row bit 3; the second half step 4 KiB further.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     unsigned a_off[4];
     {
         const int row = 8 * g + q;
         const int key = (row & 3) | (((row >> 3) & 1) << 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_off[i] = WW_DY_BASE + (unsigned)(row * 256 + (((wm * 4 + i) ^ key) << 5) + 8 * pp);
+        for (int i = 0; i < 4; ++i) a_off[i] = DY_BASE + (unsigned)(row * 256 + (((wm * 4 + i) ^ key) << 5) + 8 * pp);
     }
     unsigned x_cst[9], x_dl[9];                        // per run: byte offset of tap j's first row relative to the step's block (swizzle folded in); second row - first
     Cursor cc;
@@ -236,7 +222,7 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int c = 8 * g + q + (kh - 1) * W1 + (kw - 1) - WW_SP * cc.D;       // in [-64 D, 31]
+                const int c = 8 * g + q + (kh - 1) * W1 + (kw - 1) - WW_SP * cc.D;       // in [-128 D, 63]
                 const int c4 = c + 4;
                 const int key = ((c >> 1) & 1) | (((c >> 3) & 1) << 1), key4 = ((c4 >> 1) & 1) | (((c4 >> 3) & 1) << 1);
                 const int lo = c * 128 + ((wk ^ key) << 5) + 8 * pp, hi = c4 * 128 + ((wk ^ key4) << 5) + 8 * pp;
@@ -258,52 +244,60 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     // ---- prologue: WW_LA steps in flight
 #pragma unroll
     for (int i = 0; i < WW_LA; ++i) issue_step();
-    unsigned xc_ring = WW_XRING, dyc_ring = 0;         // xc_ring: ring offset of the (even) step's block + WW_XRING (keeps the sums below non-negative)
-    unsigned xl[9];                                    // first-row address of tap j in the even step of the pair; the odd step reads 4 KiB further
-    auto step = [&](auto odd_c) {
-        constexpr bool ODD = decltype(odd_c)::value;
-        // the step has landed once at most the two younger steps' pieces (two per wave and step) are in flight
-        if (p.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (WW_LA - 1)) : "memory");
-        if (EXP != 2) __builtin_amdgcn_s_barrier();    // every wave's pieces; and every wave has left the step before
-        const bool mul = cc.k - 2 * cc.D >= cc.s_lo && !(p.dbg & 2);
-        if (ISSUE_AT == 0 || !mul) { if (!(p.dbg & 1)) issue_step(); }       // into the dY stage / ring block the multiply loop no longer reads
-        if (!ODD) {
+    unsigned xc_ring = XRING, dyc_ring = 0;            // xc_ring: ring offset of the step's block + XRING (keeps the sums below non-negative)
+    const bool early = wave < 4;                       // the wave of each SIMD that stages right behind the barrier
+
+    // one step: MUL = false for the load-only steps at the start of a run
+    auto step = [&](auto mul_c) {
+        constexpr bool MUL = decltype(mul_c)::value && !(EXP & 2);
+        // the step has landed once at most the next step's pieces are in flight: 3 per wave, 4 when that step fills ring block 0
+        if (xc_ring == 2 * XRING - WW_XBLK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's pieces; and every wave has left the step before
+        if (!(EXP & 1) && (early || !MUL)) issue_step();      // into the dY stage / ring block the multiply loop no longer reads
+        if (MUL) {
+            unsigned xl[9];
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const unsigned a = xc_ring + x_cst[j], a2 = a - WW_XRING;      // mod WW_XRING: the sum is in [0, 2 WW_XRING)
+                const unsigned a = xc_ring + x_cst[j], a2 = a - XRING;         // mod XRING: the sum is in [0, 2 XRING)
                 xl[j] = a < a2 ? a : a2;
             }
-        }
-        if (mul) {
-            s16x8 af[4];
+            const bool bias_now = do_bias && bias_turn == cb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const unsigned a = dyc_ring + a_off[i]; af[i] = read_tr_at(a, a + 1024u); }
-            if (do_bias && bias_turn == cb)            // BiasAddGrad on the matrix cores: dY^T x ones = the column sums of dY in every column
-                accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk == 0 ? af[0] : wk == 1 ? af[1] : wk == 2 ? af[2] : af[3]),
-                                                               __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
+            for (int hs = 0; hs < 2; ++hs) {
+                const unsigned xo = hs * 4096u, ao = dyc_ring + hs * 8192u;
+                s16x8 af[4], bf[3];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const unsigned h = xl[j] + x_dl[j];
-                const s16x8 bf = EXP == 1 ? af[j & 3] : ODD ? read_tr_at(xl[j] + WW_XBLK, h + WW_XBLK) : read_tr_at(xl[j], h);
+                for (int i = 0; i < 4; ++i) af[i] = read_tr_at(ao + a_off[i], ao + a_off[i] + 1024u);
+                bf[0] = read_tr_at(xl[0] + xo, xl[0] + x_dl[0] + xo);
+                bf[1] = read_tr_at(xl[1] + xo, xl[1] + x_dl[1] + xo);
+                if (bias_now)                          // BiasAddGrad on the matrix cores: dY^T x ones = the column sums of dY in every column
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk == 0 ? af[0] : wk == 1 ? af[1] : wk == 2 ? af[2] : af[3]),
+                                                                   __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf), acc[i][j], 0, 0, 0);
-                if (ISSUE_AT != 0 && j + 1 == ISSUE_AT) { if (!(p.dbg & 1)) issue_step(); }
+                for (int j = 0; j < 9; ++j) {
+                    if (j + 2 < 9) bf[(j + 2) % 3] = read_tr_at(xl[j + 2] + xo, xl[j + 2] + x_dl[j + 2] + xo);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j % 3]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (hs == 0 && !(EXP & 1) && !early) issue_step();
             }
         }
-        if (ODD) xc_ring = xc_ring == 2 * WW_XRING - 2 * WW_XBLK ? WW_XRING : xc_ring + 2 * WW_XBLK;
+        xc_ring = xc_ring == 2 * XRING - WW_XBLK ? XRING : xc_ring + WW_XBLK;
         dyc_ring = dyc_ring == (WW_NDY - 1) * WW_DYST ? 0u : dyc_ring + WW_DYST;
         bias_turn = bias_turn + 1 == p.ncb ? 0 : bias_turn + 1;
-        if (++cc.k == cc.k_end) {
-            next_run(cc, cc.g + 1);
-            if (!cc.done) run_consts();
-        }
     };
+    while (!cc.done) {
+        const int n_load = cc.s_lo + 2 * cc.D - cc.k;  // load-only steps of this run (2 D)
 #pragma unroll 1
-    for (int st = 0; st < T; st += 2) {
-        step(std::false_type{});
-        step(std::true_type{});
+        for (int i = 0; i < n_load; ++i) step(std::false_type{});
+        const int n_mul = cc.k_end - cc.k - n_load;
+#pragma unroll 1
+        for (int i = 0; i < n_mul; ++i) step(std::true_type{});
+        next_run(cc, cc.g + 1);
+        if (!cc.done) run_consts();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
 
@@ -340,7 +334,7 @@ bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
             s.in_img_stride != (long long)s.Hin * s.in_row_stride) return false;
         const long long cells = (long long)s.Hout * s.Wout;
         if (s.out_off != 0 || s.out_img_stride != cells * d->out_ld || s.out_step > 1) return false;          // dense dY
-        if (s.Win < 1 || s.Hin < 1 || ww_lds_bytes(2 * ((s.Win + 2 + WW_SP - 1) / WW_SP) + 2 + 3 + 1, 3) > WW_LDS_MAX) return false;   // at least LA = 3
+        if (s.Win < 1 || s.Hin < 1 || ww_lds_bytes((s.Win + 2 + WW_SP - 1) / WW_SP) > WW_LDS_MAX) return false;
         if (s.in_elems * 2 >= (long long)WW_OOB || s.out_elems * 2 >= (long long)WW_OOB) return false;
         const long long Mp = (long long)d->batch * (s.Hout + 1) * (s.Wout + 1);        // the padded stream
         if (Mp >= (1ll << 24) - 64) return false;
@@ -348,7 +342,7 @@ bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
     }
     const long long ntiles = (long long)(d->N / 128) * (d->Crun / 64);
     long long S = 8 * (32 / ntiles > 1 ? 32 / ntiles : 1);
-    while (S > 8 && stages / S < 24) S -= 8;           // short pixel ranges: fewer, longer splits (every split pays 2 D steps of run-in)
+    while (S > 8 && stages / S < 12) S -= 8;           // short pixel ranges: fewer, longer splits (every split pays 2 D steps of run-in)
     if (stages < 8) return false;
     *S_out = (int)S;
     *stages_out = stages;
@@ -375,6 +369,7 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
     WWParams p;
     memset(&p, 0, sizeof(p));
     long long sb = 0;
+    int Dmax = 1;
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
         if (!s.in || !s.out || ((uintptr_t)s.in & 15) || ((uintptr_t)s.out & 15)) return 1;
@@ -390,6 +385,7 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
         g.stage_begin = (int)sb;
         g.nst = (int)((Mp + WW_SP - 1) / WW_SP);
         g.D = (s.Win + 2 + WW_SP - 1) / WW_SP;
+        Dmax = g.D > Dmax ? g.D : Dmax;
         g.cells_p = (unsigned)((s.Hin + 1) * (s.Win + 1));
         magic24(g.cells_p, &g.mg_cells, &g.sh_cells);
         magic24((unsigned)s.Win + 1u, &g.mg_w1, &g.sh_w1);
@@ -407,38 +403,28 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
     p.N = d->N; p.C = d->Crun; p.Ktot = Ktot;
     p.pix_b = d->pix_stride * 2;
     p.dy_ld_b = d->out_ld * 2;
-    p.dbg = rtn_env_int("RTN_WGRAD_WIN_DBG", 0);
     // every split must own at least one stage: the finish adds all S slabs
     const int S_used = (int)((stages + p.stages_per_split - 1) / p.stages_per_split);
-    int Dmax = 1;
-    for (int i = 0; i < d->ngroups; ++i) Dmax = p.g[i].D > Dmax ? p.g[i].D : Dmax;
-    // the deepest lookahead the LDS holds for this launch's widest level (RTN_WGRAD_WIN_LA overrides: 3, 6 or 9)
-    auto nblk_for = [&](int la) { return (2 * Dmax + 1 + la + 1 + 1) & ~1; };
-    int la = 9;
-    while (la > 3 && ww_lds_bytes(nblk_for(la), la) > WW_LDS_MAX) la -= 3;
-    { const int v = rtn_env_int("RTN_WGRAD_WIN_LA", 0); if ((v == 3 || v == 6 || v == 9) && v <= la) la = v; }
-    const int nblk = nblk_for(la), lds_bytes = ww_lds_bytes(nblk, la);
+    const int lds_bytes = ww_lds_bytes(Dmax);
     if (lds_bytes > WW_LDS_MAX) return 1;
-    p.xring = (unsigned)nblk * WW_XBLK;
-    const bool top = rtn_env_int("RTN_WGRAD_WIN_ISSUE", 3) == 0;
+    p.xring = (unsigned)ww_nblk(Dmax) * WW_XBLK;
     const unsigned grid = (unsigned)(p.ntiles * ((S + 7) / 8) * 8);
-#define RTN_WW_LAUNCH(IA_, LA_) RTN_WW_LAUNCH_E(IA_, LA_, 0)
-#define RTN_WW_LAUNCH_E(IA_, LA_, E_)                                                                                                   \
+#define RTN_WW_LAUNCH(E_)                                                                                                         \
     do {                                                                                                                          \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<IA_, LA_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX)); \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX)); \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((conv_wgrad_win_kernel<IA_, LA_, E_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);             \
+        hipLaunchKernelGGL((conv_wgrad_win_kernel<E_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);                   \
     } while (0)
-    const int exp_ = rtn_env_int("RTN_WGRAD_WIN_EXP", 0);
-    if (exp_ == 1) RTN_WW_LAUNCH_E(3, 6, 1);
-    else if (exp_ == 2) RTN_WW_LAUNCH_E(3, 6, 2);
-    else if (top) { if (la == 9) RTN_WW_LAUNCH(0, 9); else if (la == 6) RTN_WW_LAUNCH(0, 6); else RTN_WW_LAUNCH(0, 3); }
-    else     { if (la == 9) RTN_WW_LAUNCH(3, 9); else if (la == 6) RTN_WW_LAUNCH(3, 6); else RTN_WW_LAUNCH(3, 3); }
+    switch (rtn_env_int("RTN_WGRAD_WIN_DBG", 0)) {     // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
+        case 1: RTN_WW_LAUNCH(1); break;
+        case 2: RTN_WW_LAUNCH(2); break;
+        case 3: RTN_WW_LAUNCH(3); break;
+        default: RTN_WW_LAUNCH(0); break;
+    }
 #undef RTN_WW_LAUNCH
-#undef RTN_WW_LAUNCH_E
     RTN_CHECK_LAUNCH(h, "conv_wgrad_win_kernel");
     const rtn_wgrad_frag_t fr = {p.ncb, p.C, Ktot};
     return rtn_wgrad_finish(h, dW, p.slab, S_used, (long long)d->N * Ktot, db, p.bslab, d->N, db ? db_n : 0, S_used * p.ncb, &fr);

@@ -284,6 +284,7 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
 
     def run(halo):
         monkeypatch.setenv("RTN_WGRAD_HALO", "1" if halo else "0")
+        monkeypatch.setenv("RTN_WGRAD_WIN", "0")
         wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
         dW = torch.full((cout, 9 * cin), 0.5, dtype=torch.float32, device=DEV)
@@ -312,7 +313,7 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
     ([(25, 42)], 256, 256, 2, False),          # P5 / res4 branch2b-like, no bias
     ([(40, 67)], 128, 128, 3, True),           # res3 branch2b: 2 output tiles, 128 splits asked for
     ([(13, 21)], 512, 512, 3, False),          # res5 branch2b: 32 output tiles, 8 splits
-    ([(7, 300)], 64, 128, 1, True),            # image rows of 300 pixels: D = 10; one channel tile
+    ([(7, 250)], 64, 128, 1, True),            # image rows of 250 pixels: D = 4, the widest the LDS holds; one channel tile
     ([(3, 5), (64, 64)], 128, 256, 2, True),   # a tiny level first: its stages end inside the first split
 ])
 def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bias):
@@ -393,6 +394,7 @@ def test_wgrad_general_kernels_repeat_bit_for_bit(pkg, handle, monkeypatch, dtyp
     tdt, code = DT[dtype]
     for kk, v in env.items():
         monkeypatch.setenv(kk, v)
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")               # the general kernels are the subject here
     g = torch.Generator().manual_seed(9)
     x = torch.randn(B, H, W, cin, generator=g).to(tdt).to(DEV).contiguous()
     dy = torch.randn(B, H, W, cout, generator=g).to(tdt).to(DEV).contiguous()
@@ -574,6 +576,7 @@ def test_wgrad_dma_kernel_cases(pkg, handle, monkeypatch, case):
     """RTN_WGRAD_DMA=2 sends every bf16 layer with more than 128 filters to the 256 x 256 LDS-DMA wgrad kernel (by default only
     layers with >= 2048 pixel tiles take it): the same cases as above, incl. stride 2 and the fused bias gradient."""
     monkeypatch.setenv("RTN_WGRAD_DMA", "2")
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
     test_dgrad_and_wgrad(pkg, handle, "bf16", case)
 
 
@@ -609,6 +612,7 @@ def test_wgrad_dma_grouped_levels_match_the_small_kernel(pkg, handle, monkeypatc
     wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
     got = {}
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
     for mode in ("0", "2"):
         monkeypatch.setenv("RTN_WGRAD_DMA", mode)
         dW = torch.zeros(256, 9 * cin, dtype=torch.float32, device=DEV)
@@ -680,6 +684,7 @@ def test_wgrad_ring_kernel_equals_the_two_stage_kernel_bit_for_bit(pkg, handle, 
         d.g[gi] = grp
         off += H * W
     monkeypatch.setenv("RTN_WGRAD_DMA", "2")
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
     got = {}
     for ring in ("0", "1", "1"):
         monkeypatch.setenv("RTN_WGRAD_RING", ring)

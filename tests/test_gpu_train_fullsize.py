@@ -115,8 +115,8 @@ def test_fp32_training_step_800x1333_batch2_against_float64_autograd(pkg):
 
 # Which kernel each backward op takes at batch 16 x 800 x 1333 in bf16 (rtn_debug_last_conv_impl / rtn_debug_last_wgrad_impl;
 # dgrad: 2 = 256-row LDS-DMA per tap, 4 = persistent 8-phase 3x3, 5 = persistent 1x1; wgrad: 1 = 3x3 halo kernel, 2 = 256 x 256
-# LDS-DMA, 3 = 128 x 128 LDS-DMA).  The cost models that choose are in csrc/rtn_conv.hip (conv_launch) and rtn_backward.hip
-# (wgrad_plan, wgrad_takes_halo); DESIGN.md §3.3.
+# LDS-DMA, 3 = 128 x 128 LDS-DMA, 4 = the nine-tap window kernel).  The cost models that choose are in csrc/rtn_conv.hip
+# (conv_launch) and rtn_backward.hip (wgrad_plan, wgrad_takes_win, wgrad_takes_halo); DESIGN.md §3.3.
 EXPECTED_IMPLS = {
     # data gradients: the tower / pyramid / bottleneck 3x3 layers on the persistent 8-phase kernel, the 1x1 layers with >= 128
     # output channels on the persistent 1x1 kernel (residual + ReLU-mask epilogues), the 64-channel and stride-2 forms on generations 1-2
@@ -127,11 +127,12 @@ EXPECTED_IMPLS = {
     ("dgrad", "res5b_branch2a"): 5, ("dgrad", "res5b_branch2b"): 2, ("dgrad", "res5b_branch2c"): 5,
     ("dgrad", "res2b_branch2b"): 2, ("dgrad", "res2b_branch2c"): 1, ("dgrad", "P6"): 2, ("dgrad", "P7"): 1,
     ("dgrad", "pyramid_regression"): 2, ("dgrad", "pyramid_classification"): 2,
-    # weight gradients: 256 x 256 LDS-DMA kernel at >= 2048 pixel tiles (towers, P3, C3_reduced, res3a_branch1), the 3x3 halo kernel
-    # for the 128 / 256-channel 3x3 layers below that, the 128 x 128 LDS-DMA kernel for the rest
-    ("wgrad", "pyramid_regression_0"): 2, ("wgrad", "pyramid_classification_3"): 2, ("wgrad", "P3"): 2, ("wgrad", "C3_reduced"): 2,
-    ("wgrad", "res3a_branch1"): 2, ("wgrad", "P4"): 1, ("wgrad", "res3b_branch2b"): 1, ("wgrad", "res4b_branch2b"): 1,
-    ("wgrad", "res4f_branch2b"): 1, ("wgrad", "res5b_branch2b"): 3, ("wgrad", "res2b_branch2b"): 3, ("wgrad", "res4b_branch2a"): 3,
+    # weight gradients: the nine-tap window kernel for the stride-1 3x3 layers with >= 128 channels (towers, P3, P4, res3-res5
+    # branch2b), the 256 x 256 LDS-DMA kernel for the 1x1 layers with >= 2048 pixel tiles (C3_reduced, res3a_branch1), the
+    # 128 x 128 LDS-DMA kernel for the rest
+    ("wgrad", "pyramid_regression_0"): 4, ("wgrad", "pyramid_classification_3"): 4, ("wgrad", "P3"): 4, ("wgrad", "C3_reduced"): 2,
+    ("wgrad", "res3a_branch1"): 2, ("wgrad", "P4"): 4, ("wgrad", "res3b_branch2b"): 4, ("wgrad", "res4b_branch2b"): 4,
+    ("wgrad", "res4f_branch2b"): 4, ("wgrad", "res5b_branch2b"): 4, ("wgrad", "res2b_branch2b"): 3, ("wgrad", "res4b_branch2a"): 3,
     ("wgrad", "conv1"): 3, ("wgrad", "pyramid_regression"): 3, ("wgrad", "P6"): 3,
 }
 

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, bench
 L = importlib.import_module(bench.PKG + "._lib")
 SHAPES = {"tower": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 256), "p3": ([(100, 167)], 256, 256),
-          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512)}
+          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512), "p5": ([(25, 42)], 256, 256)}
 name = sys.argv[1] if len(sys.argv) > 1 else "tower"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 levels, cin, cout = SHAPES[name]
