@@ -1317,7 +1317,8 @@ static bool wgrad_takes_win(const rtn_conv_desc_t* d, const WgradPlan& w) {
     const int knob = rtn_env_int("RTN_WGRAD_WIN", -1);
     if (knob == 0 || rtn_wgrad_win_workspace_bytes(d) == 0) return false;
     if (knob > 0) return true;
-    return w.tiles * (long long)(d->N / 128) * (d->Crun / 64) >= 3000;
+    // (the 64-filter form, res2 branch2b and the head outputs: half the work per tile)
+    return w.tiles * (long long)(d->N == 64 ? 1 : 2 * (d->N / 128)) * (d->Crun / 64) >= 6000;
 }
 
 // workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel

@@ -51,7 +51,7 @@ void rtn_env_sync();
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
                        long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8 = nullptr);
 size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);
-struct rtn_wgrad_frag_t { int ncb, C, Ktot; };          // slabs in the accumulator-fragment order of rtn_wgrad_win.hip (ncb > 0)
+struct rtn_wgrad_frag_t { int ncb, C, Ktot, wpt, co_tile; };   // slabs in the accumulator-fragment order of rtn_wgrad_win.hip (ncb > 0): waves per tile in the slab (8 / 4), filters per tile (128 / 64)
 int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n,
                      int bS = 0 /* parts of bslab when not S */, const rtn_wgrad_frag_t* frag = nullptr);
 // rtn_wgrad_win.hip: all nine taps of a 128-filter x 64-channel block per workgroup over a sliding window of the input

@@ -292,15 +292,15 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ d
             for (int l = 1; l < SL; ++l) { const float4 a = part[l][c]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
             if (fr.ncb > 0) {
                 // slabs in accumulator-fragment order (rtn_wgrad_win.hip): float4 i = [tile][wave][tap j][i4][lane] holds rows
-                // n .. n + 3 of ONE column: n = 128 tn + 64 wm + 16 i4 + 4 (lane / 16), k = j C + 64 cb + 16 wk + lane % 16
+                // n .. n + 3 of ONE column: n = co_tile tn + 64 wm + 16 i4 + 4 (lane / 16), k = j C + 64 cb + 16 wk + lane % 16
                 const int lane = (int)(i & 63);
                 const unsigned f = (unsigned)(i >> 6);                  // NK < 2^32
                 const int i4 = (int)(f & 3);
                 const unsigned t2 = f >> 2, t3 = t2 / 9u;
                 const int j = (int)(t2 - t3 * 9u);
-                const int wave = (int)(t3 & 7), tile = (int)(t3 >> 3);
+                const int tile = (int)(t3 / (unsigned)fr.wpt), wave = (int)t3 - tile * fr.wpt;
                 const int tn = tile / fr.ncb, cb = tile - tn * fr.ncb;
-                const int n = 128 * tn + 64 * (wave >> 2) + 16 * i4 + 4 * (lane >> 4);
+                const int n = fr.co_tile * tn + 64 * (wave >> 2) + 16 * i4 + 4 * (lane >> 4);
                 const int k = j * fr.C + 64 * cb + 16 * (wave & 3) + (lane & 15);
                 float* o = dW + (size_t)n * fr.Ktot + k;
                 o[0] += v.x; o[fr.Ktot] += v.y; o[2 * (size_t)fr.Ktot] += v.z; o[3 * (size_t)fr.Ktot] += v.w;
@@ -371,7 +371,7 @@ int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long l
     if (!dW || !slab || S < 1 || NK < 4 || NK % 4) return rtn_fail(h, RTN_EINVAL, "wgrad finish: bad argument");
     const int nb = db ? db_n : 0;
     if (bS < 1) bS = S;
-    rtn_wgrad_frag_t fr = {0, 0, 0};
+    rtn_wgrad_frag_t fr = {0, 0, 0, 8, 128};
     if (frag) fr = *frag;
 #define RTN_WF(SL_)                                                                                               \
     do {                                                                                                          \

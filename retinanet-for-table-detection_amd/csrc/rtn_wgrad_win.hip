@@ -31,6 +31,10 @@
 //     ones fragment that the channel tiles x 4 waves sharing a dY fragment take in turns.
 // LDS: X ring (2 D + 4 blocks of 8 KiB) + mirror 8 KiB + dY 48 KiB = 136 KiB for rows of up to 190 pixels (D = 3), 152 KiB up to 254.
 // One workgroup of 8 waves = 2 (filter halves of 64) x 4 (channel slices of 16) per CU.
+// PS = true is the form for layers with 64 filters (res2 branch2b; the head outputs, whose dY is padded to 64 columns and lies
+// level after level inside one tensor): the tile is 64 filters x 64 channels x 9 taps, the two wave groups take the two 32-slot
+// halves of a step instead of two filter halves and add their accumulators through LDS at the end; dY rows are 128 B (24 KiB of
+// stages), which leaves room for a ring of 16 blocks: image rows of up to 382 pixels.
 #include "rtn_internal.h"
 #include <type_traits>
 
@@ -47,17 +51,18 @@ constexpr int WW_THREADS = 512;
 constexpr int WW_SP = 64;                              // pixel slots per step
 constexpr unsigned WW_XBLK = WW_SP * 128;              // one X block: 64 slots x 64 channels = 8 KiB
 constexpr unsigned WW_MIRROR = WW_XBLK;                // ring block 0 once more behind the ring
-constexpr unsigned WW_DYST = WW_SP * 256;              // one dY stage: 64 slots x 128 filters = 16 KiB
 constexpr int WW_LA = 2;                               // steps a load runs ahead of its use
 constexpr int WW_NDY = WW_LA + 1;
 constexpr int WW_LDS_MAX = 160 * 1024;
+constexpr unsigned ww_dyst(bool ps) { return WW_SP * (ps ? 128u : 256u); }   // one dY stage: 64 slots x 128 (64) filters = 16 (8) KiB
 constexpr int ww_nblk(int D) { return 2 * D + 1 + WW_LA + 1; }
-constexpr int ww_lds_bytes(int D) { return (int)(ww_nblk(D) * WW_XBLK + WW_MIRROR + WW_NDY * WW_DYST); }
+constexpr int ww_lds_bytes(int D, bool ps) { return (int)(ww_nblk(D) * WW_XBLK + WW_MIRROR + WW_NDY * ww_dyst(ps)); }
 
 struct WWSeg {
     const char* x;
     const char* dy;
     unsigned x_bytes, dy_bytes;
+    unsigned x_img_b, dy_img_b;              // bytes between the images of x / dY
     int H, W, Mp;                            // Mp: slots of the padded stream, batch * (H + 1) * (W + 1)
     int stage_begin, nst, D;                 // first output stage (64 slots) of the level in the launch, their number, ceil((W + 2) / 64)
     unsigned cells_p, mg_cells, sh_cells;    // (H + 1) * (W + 1) and the multiply-shift pair dividing by it (exact below 2^24)
@@ -66,10 +71,10 @@ struct WWSeg {
 
 struct WWParams {
     WWSeg g[RTN_MAX_GROUPS];
-    float* slab;                  // [S][tile][wave][tap][4][64 lanes][4]: accumulator fragments
+    float* slab;                  // [S][tile][wave (PS: 4 waves)][tap][4][64 lanes][4]: accumulator fragments
     float* bslab;                 // [S * ncb][N] partial column sums of dY (fused BiasAddGrad) or null
     int ngroups, total_stages, stages_per_split, S;
-    int ntiles, ncb;              // output tiles = (N / 128) x ncb channel blocks of 64
+    int ntiles, ncb;              // output tiles = (N / 128, PS: 1) x ncb channel blocks of 64
     int N, C, Ktot;
     int pix_b, dy_ld_b;
     unsigned xring;               // bytes of the X ring
@@ -110,9 +115,11 @@ struct Cursor {
 };
 
 // EXP (timing experiments, wrong results): 1 = no staging in the loop, 2 = no fragment reads / MFMAs, 3 = neither
-template <int EXP>
+template <int EXP, bool PS>
 __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr unsigned WW_DYST = ww_dyst(PS), DY_ROW = PS ? 128u : 256u, DY_HALF = 32u * DY_ROW;
+    constexpr int NPIECE = PS ? 2 : 3;                 // LDS-DMA pieces per wave and step (one more when the block has a mirror)
     const unsigned XRING = p.xring, DY_BASE = XRING + WW_MIRROR;
     // workgroup -> (output tile, pixel split): the tiles of one split sit on one XCD
     const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     ghi = ghi < p.total_stages ? ghi : p.total_stages;
     if (split >= p.S || glo >= ghi) return;
     const int tn = tile / p.ncb, cb = tile - tn * p.ncb;
-    const int n0 = tn * 128, c0 = cb * 64;
+    const int n0 = PS ? 0 : tn * 128, c0 = cb * 64;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -146,50 +153,53 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     // ---- staging role: three pieces per wave and step.  dY: rows 4 wave + lane / 16 and that + 32 (4 rows of 256 B per piece),
     // LDS chunk position lane % 16.  X: rows 8 wave + lane / 8 (8 rows of 128 B), chunk position lane % 8; a fourth piece writes the
     // X rows once more behind the ring when the block is ring block 0.
-    const int dy_row = 4 * wave + (lane >> 4);
-    unsigned dy_col;
-    {
-        const int key = (dy_row & 3) | (((dy_row >> 3) & 1) << 2), cpos = lane & 15;
-        dy_col = (unsigned)((n0 + ((((cpos >> 1) ^ key) << 1) | (cpos & 1)) * 8) * 2);
-    }
+    // (PS: dY rows are 128 B like the X rows: one piece of 8 rows per wave, the X swizzle.)
     const int x_row = 8 * wave + (lane >> 3);
-    unsigned x_col;
+    unsigned x_col, dy_col;
+    const int dy_row = PS ? x_row : 4 * wave + (lane >> 4);
     {
         const int key = ((x_row >> 1) & 1) | (((x_row >> 3) & 1) << 1), cpos = lane & 7;
-        x_col = (unsigned)((c0 + ((((cpos >> 1) ^ key) << 1) | (cpos & 1)) * 8) * 2);
+        const unsigned chunk = (unsigned)((((cpos >> 1) ^ key) << 1) | (cpos & 1));
+        x_col = (unsigned)((c0 + chunk * 8) * 2);
+        dy_col = chunk * 16u;
+    }
+    if (!PS) {
+        const int key = (dy_row & 3) | (((dy_row >> 3) & 1) << 2), cpos = lane & 15;
+        dy_col = (unsigned)((n0 + ((((cpos >> 1) ^ key) << 1) | (cpos & 1)) * 8) * 2);
     }
     Cursor lc;                                         // the staging cursor: WW_LA steps ahead of the multiplying one
     next_run(lc, 0);
     i32x4 xs = make_srd(p.g[0].x, p.g[0].x_bytes), ys = make_srd(p.g[0].dy, p.g[0].dy_bytes);
     int gH = 1, gW = 1, gMp = 0;
-    unsigned g_cells = 1, g_mgc = 0, g_shc = 0, g_mgw = 0, g_shw = 0;
+    unsigned g_cells = 1, g_mgc = 0, g_shc = 0, g_mgw = 0, g_shw = 0, g_ximg = 0, g_dyimg = 0;
     auto load_level = [&](int gi) {
         const WWSeg& G = p.g[gi < p.ngroups ? gi : 0];
         xs = make_srd(G.x, G.x_bytes);
         ys = make_srd(G.dy, G.dy_bytes);
-        gH = G.H; gW = G.W; gMp = G.Mp;
+        gH = G.H; gW = G.W; gMp = G.Mp; g_ximg = G.x_img_b; g_dyimg = G.dy_img_b;
         g_cells = G.cells_p; g_mgc = G.mg_cells; g_shc = G.sh_cells; g_mgw = G.mg_w1; g_shw = G.sh_w1;
     };
     load_level(lc.g);
     unsigned xl_ring = 0, dyl_ring = 0;
     // padded slot -> byte offset of its pixel (or WW_OOB for the padding column / row and for slots outside the level)
-    auto slot_offset = [&](int u, bool live, unsigned pitch_b, unsigned col) -> unsigned {
+    auto slot_offset = [&](int u, bool live, unsigned img_b, unsigned pitch_b, unsigned col) -> unsigned {
         const unsigned uu = (unsigned)(u < 0 ? 0 : u);
         const unsigned b = __umulhi(uu, g_mgc) >> g_shc, rem = uu - b * g_cells;
         const unsigned y = __umulhi(rem, g_mgw) >> g_shw, x = rem - y * ((unsigned)gW + 1u);
         const bool ok = live && u >= 0 && u < gMp && x < (unsigned)gW && y < (unsigned)gH;
-        const unsigned real = uu - b * (unsigned)(gH + gW + 1) - y;      // one padding slot per completed row, one padding row per image
-        return ok ? real * pitch_b + col : WW_OOB;
+        return ok ? b * img_b + (rem - y) * pitch_b + col : WW_OOB;      // rem - y: the pixel's index in its image (one padding slot per completed row)
     };
     auto issue_step = [&]() {
         const bool live = !lc.done;
         const int s = lc.k - 2 * lc.D;
         const bool dy_live = live && s >= lc.s_lo;
-        const unsigned v0 = slot_offset(s * WW_SP + dy_row, dy_live, (unsigned)p.dy_ld_b, dy_col);
-        const unsigned v1 = slot_offset(s * WW_SP + 32 + dy_row, dy_live, (unsigned)p.dy_ld_b, dy_col);
-        const unsigned vx = slot_offset((lc.k - lc.D) * WW_SP + x_row, live, (unsigned)p.pix_b, x_col);
+        const unsigned v0 = slot_offset(s * WW_SP + dy_row, dy_live, g_dyimg, (unsigned)p.dy_ld_b, dy_col);
         dma16(ys, v0, DY_BASE + dyl_ring + (unsigned)wave * 1024u);
-        dma16(ys, v1, DY_BASE + dyl_ring + 8192u + (unsigned)wave * 1024u);
+        if (!PS) {
+            const unsigned v1 = slot_offset(s * WW_SP + 32 + dy_row, dy_live, g_dyimg, (unsigned)p.dy_ld_b, dy_col);
+            dma16(ys, v1, DY_BASE + dyl_ring + 8192u + (unsigned)wave * 1024u);
+        }
+        const unsigned vx = slot_offset((lc.k - lc.D) * WW_SP + x_row, live, g_ximg, (unsigned)p.pix_b, x_col);
         dma16(xs, vx, xl_ring + (unsigned)wave * 1024u);
         if (xl_ring == 0) dma16(xs, vx, XRING + (unsigned)wave * 1024u);
         xl_ring = xl_ring == XRING - WW_XBLK ? 0u : xl_ring + WW_XBLK;
@@ -209,9 +219,9 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     unsigned a_off[4];
     {
         const int row = 8 * g + q;
-        const int key = (row & 3) | (((row >> 3) & 1) << 2);
+        const int key = PS ? ((row >> 1) & 1) | (((row >> 3) & 1) << 1) : (row & 3) | (((row >> 3) & 1) << 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_off[i] = DY_BASE + (unsigned)(row * 256 + (((wm * 4 + i) ^ key) << 5) + 8 * pp);
+        for (int i = 0; i < 4; ++i) a_off[i] = DY_BASE + (unsigned)(row * (int)DY_ROW + ((((PS ? 0 : wm * 4) + i) ^ key) << 5) + 8 * pp);
     }
     unsigned x_cst[9], x_dl[9];                        // per run: byte offset of tap j's first row relative to the step's block (swizzle folded in); second row - first
     Cursor cc;
@@ -251,8 +261,8 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     auto step = [&](auto mul_c) {
         constexpr bool MUL = decltype(mul_c)::value && !(EXP & 2);
         // the step has landed once at most the next step's pieces are in flight: 3 per wave, 4 when that step fills ring block 0
-        if (xc_ring == 2 * XRING - WW_XBLK) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (xc_ring == 2 * XRING - WW_XBLK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
         __builtin_amdgcn_s_barrier();                  // every wave's pieces; and every wave has left the step before
         if (!(EXP & 1) && (early || !MUL)) issue_step();      // into the dY stage / ring block the multiply loop no longer reads
         if (MUL) {
@@ -264,11 +274,12 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
             }
             const bool bias_now = do_bias && bias_turn == cb;
 #pragma unroll
-            for (int hs = 0; hs < 2; ++hs) {
-                const unsigned xo = hs * 4096u, ao = dyc_ring + hs * 8192u;
+            for (int hs0 = 0; hs0 < (PS ? 1 : 2); ++hs0) {
+                const unsigned hs = PS ? (unsigned)wm : (unsigned)hs0;           // PS: the wave group's own half of the step
+                const unsigned xo = hs * 4096u, ao = dyc_ring + hs * DY_HALF;
                 s16x8 af[4], bf[3];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = read_tr_at(ao + a_off[i], ao + a_off[i] + 1024u);
+                for (int i = 0; i < 4; ++i) af[i] = read_tr_at(ao + a_off[i], ao + a_off[i] + 4u * DY_ROW);
                 bf[0] = read_tr_at(xl[0] + xo, xl[0] + x_dl[0] + xo);
                 bf[1] = read_tr_at(xl[1] + xo, xl[1] + x_dl[1] + xo);
                 if (bias_now)                          // BiasAddGrad on the matrix cores: dY^T x ones = the column sums of dY in every column
@@ -281,8 +292,9 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
                     for (int i = 0; i < 4; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j % 3]), acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (PS && j == 3 && !(EXP & 1) && !early) issue_step();
                 }
-                if (hs == 0 && !(EXP & 1) && !early) issue_step();
+                if (!PS && hs0 == 0 && !(EXP & 1) && !early) issue_step();
             }
         }
         xc_ring = xc_ring == 2 * XRING - WW_XBLK ? XRING : xc_ring + WW_XBLK;
@@ -303,7 +315,26 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
 
     // ---- this split's tile -> slab[split][tile][wave][tap j][i][lane][4]: the accumulator fragments as they lie in the registers,
     // 16 B per lane and 1 KiB per store instruction; rtn_wgrad_finish puts them in place (frag layout)
-    float* sp = p.slab + (size_t)split * p.N * p.Ktot + ((size_t)(tile * 8 + wave) * 36) * 256 + lane * 4;
+    if (PS) {
+        // the two wave groups hold the two halves of every step: waves 4-7 hand their sums to waves 0-3 through LDS (fixed order)
+        __builtin_amdgcn_s_barrier();                  // every wave has left the multiply loop
+        f32x4* ex = reinterpret_cast<f32x4*>(lds) + (size_t)wk * 37 * 64 + lane;
+        if (wm == 1) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ex[(j * 4 + i) * 64] = acc[i][j];
+            ex[36 * 64] = accb;
+        }
+        __syncthreads();
+        if (wm == 1) return;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] += ex[(j * 4 + i) * 64];
+        accb += ex[36 * 64];
+    }
+    float* sp = p.slab + (size_t)split * p.N * p.Ktot + ((size_t)(PS ? tile * 4 + wk : tile * 8 + wave) * 36) * 256 + lane * 4;
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
@@ -311,7 +342,7 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
     if (do_bias && (lane & 15) == 0) {
         const int lr = (lane >> 4) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p.bslab[((size_t)split * p.ncb + cb) * p.N + n0 + wm * 64 + 16 * wk + lr + r] = accb[r];
+        for (int r = 0; r < 4; ++r) p.bslab[((size_t)split * p.ncb + cb) * p.N + n0 + (PS ? 0 : wm * 64) + 16 * wk + lr + r] = accb[r];
     }
 }
 
@@ -324,28 +355,32 @@ void magic24(unsigned d, unsigned* mg, unsigned* sh) {
 }
 
 // Shape / layout test and the split plan (no handle: rtn_conv2d_wgrad_workspace_bytes has none; sized for the 256 CUs of an MI355X).
-bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
+// *ps_out: the 64-filter form.
+bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out, bool* ps_out) {
     if (d->dtype != RTN_BF16 || d->KH != 3 || d->KW != 3 || d->sy != 1 || d->sx != 1 || d->pad_t != 1 || d->pad_l != 1) return false;
-    if (d->N < 128 || d->N % 128 || d->Crun < 64 || d->Crun % 64 || d->pix_stride != d->Crun || d->out_ld < d->N || d->out_ld % 8) return false;
+    const bool ps = d->N == 64;
+    if ((!ps && (d->N < 128 || d->N % 128)) || d->Crun < 64 || d->Crun % 64 || d->pix_stride != d->Crun || d->out_ld < d->N || d->out_ld % 8) return false;
     long long stages = 0;
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
         if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
             s.in_img_stride != (long long)s.Hin * s.in_row_stride) return false;
         const long long cells = (long long)s.Hout * s.Wout;
-        if (s.out_off != 0 || s.out_img_stride != cells * d->out_ld || s.out_step > 1) return false;          // dense dY
-        if (s.Win < 1 || s.Hin < 1 || ww_lds_bytes((s.Win + 2 + WW_SP - 1) / WW_SP) > WW_LDS_MAX) return false;
+        // dY: pixels of an image out_ld apart, images out_img_stride apart, the level out_off into the tensor (head outputs)
+        if (s.out_step > 1 || s.out_off < 0 || s.out_off % 8 || s.out_img_stride % 8 || s.out_img_stride < cells * d->out_ld) return false;
+        if (s.Win < 1 || s.Hin < 1 || ww_lds_bytes((s.Win + 2 + WW_SP - 1) / WW_SP, ps) > WW_LDS_MAX) return false;
         if (s.in_elems * 2 >= (long long)WW_OOB || s.out_elems * 2 >= (long long)WW_OOB) return false;
         const long long Mp = (long long)d->batch * (s.Hout + 1) * (s.Wout + 1);        // the padded stream
         if (Mp >= (1ll << 24) - 64) return false;
         stages += (Mp + WW_SP - 1) / WW_SP;
     }
-    const long long ntiles = (long long)(d->N / 128) * (d->Crun / 64);
+    const long long ntiles = (ps ? 1 : (long long)(d->N / 128)) * (d->Crun / 64);
     long long S = 8 * (32 / ntiles > 1 ? 32 / ntiles : 1);
     while (S > 8 && stages / S < 12) S -= 8;           // short pixel ranges: fewer, longer splits (every split pays 2 D steps of run-in)
     if (stages < 8) return false;
     *S_out = (int)S;
     *stages_out = stages;
+    *ps_out = ps;
     return true;
 }
 
@@ -354,7 +389,8 @@ bool plan(const rtn_conv_desc_t* d, int* S_out, long long* stages_out) {
 size_t rtn_wgrad_win_workspace_bytes(const rtn_conv_desc_t* d) {
     int S;
     long long stages;
-    if (!plan(d, &S, &stages)) return 0;
+    bool ps;
+    if (!plan(d, &S, &stages, &ps)) return 0;
     return (size_t)S * d->N * ((size_t)9 * d->Crun + (size_t)(d->Crun / 64)) * sizeof(float);
 }
 
@@ -362,7 +398,8 @@ size_t rtn_wgrad_win_workspace_bytes(const rtn_conv_desc_t* d) {
 int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes) {
     int S;
     long long stages;
-    if (!plan(d, &S, &stages)) return 1;
+    bool ps;
+    if (!plan(d, &S, &stages, &ps)) return 1;
     if (!dW || ((uintptr_t)dW & 15) || !workspace || ((uintptr_t)workspace & 15)) return 1;
     const size_t need = rtn_wgrad_win_workspace_bytes(d);
     if (workspace_bytes < need) return 1;
@@ -374,12 +411,15 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
         const rtn_conv_group_t& s = d->g[i];
         if (!s.in || !s.out || ((uintptr_t)s.in & 15) || ((uintptr_t)s.out & 15)) return 1;
         const long long cells = (long long)s.Hout * s.Wout, M = cells * d->batch;
-        if (s.in_elems < M * d->Crun || s.out_elems < (M - 1) * d->out_ld + d->N) return 1;
+        if (s.in_elems < M * d->Crun) return 1;
+        if (s.out_elems < (long long)(d->batch - 1) * s.out_img_stride + s.out_off + (cells - 1) * d->out_ld + d->N) return 1;
         WWSeg& g = p.g[i];
         g.x = (const char*)s.in;
-        g.dy = (const char*)s.out;
+        g.dy = (const char*)s.out + s.out_off * 2;
         g.x_bytes = (unsigned)(s.in_elems * 2);
-        g.dy_bytes = (unsigned)(s.out_elems * 2);
+        g.dy_bytes = (unsigned)((s.out_elems - s.out_off) * 2);
+        g.x_img_b = (unsigned)(s.in_img_stride * 2);
+        g.dy_img_b = (unsigned)(s.out_img_stride * 2);
         const long long Mp = (long long)d->batch * (s.Hin + 1) * (s.Win + 1);
         g.H = s.Hin; g.W = s.Win; g.Mp = (int)Mp;
         g.stage_begin = (int)sb;
@@ -399,33 +439,34 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
     p.total_stages = (int)stages;
     p.stages_per_split = (int)((stages + S - 1) / S);
     p.S = S;
-    p.ntiles = (d->N / 128) * p.ncb;
+    p.ntiles = (ps ? 1 : d->N / 128) * p.ncb;
     p.N = d->N; p.C = d->Crun; p.Ktot = Ktot;
     p.pix_b = d->pix_stride * 2;
     p.dy_ld_b = d->out_ld * 2;
     // every split must own at least one stage: the finish adds all S slabs
     const int S_used = (int)((stages + p.stages_per_split - 1) / p.stages_per_split);
-    const int lds_bytes = ww_lds_bytes(Dmax);
+    int lds_bytes = ww_lds_bytes(Dmax, ps);
     if (lds_bytes > WW_LDS_MAX) return 1;
+    if (ps && lds_bytes < 4 * 37 * 1024) lds_bytes = 4 * 37 * 1024;       // the exchange of the two wave groups' accumulators
     p.xring = (unsigned)ww_nblk(Dmax) * WW_XBLK;
     const unsigned grid = (unsigned)(p.ntiles * ((S + 7) / 8) * 8);
-#define RTN_WW_LAUNCH(E_)                                                                                                         \
+#define RTN_WW_LAUNCH(E_, PS_)                                                                                                    \
     do {                                                                                                                          \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<E_>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX)); \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<E_, PS_>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX)); \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        hipLaunchKernelGGL((conv_wgrad_win_kernel<E_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);                   \
+        hipLaunchKernelGGL((conv_wgrad_win_kernel<E_, PS_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);              \
     } while (0)
-    switch (rtn_env_int("RTN_WGRAD_WIN_DBG", 0)) {     // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
-        case 1: RTN_WW_LAUNCH(1); break;
-        case 2: RTN_WW_LAUNCH(2); break;
-        case 3: RTN_WW_LAUNCH(3); break;
-        default: RTN_WW_LAUNCH(0); break;
+    const int dbg = rtn_env_int("RTN_WGRAD_WIN_DBG", 0);    // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
+    if (ps) {
+        if (dbg == 1) RTN_WW_LAUNCH(1, true); else if (dbg == 2) RTN_WW_LAUNCH(2, true); else if (dbg == 3) RTN_WW_LAUNCH(3, true); else RTN_WW_LAUNCH(0, true);
+    } else {
+        if (dbg == 1) RTN_WW_LAUNCH(1, false); else if (dbg == 2) RTN_WW_LAUNCH(2, false); else if (dbg == 3) RTN_WW_LAUNCH(3, false); else RTN_WW_LAUNCH(0, false);
     }
 #undef RTN_WW_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_wgrad_win_kernel");
-    const rtn_wgrad_frag_t fr = {p.ncb, p.C, Ktot};
+    const rtn_wgrad_frag_t fr = {p.ncb, p.C, Ktot, ps ? 4 : 8, ps ? 64 : 128};
     return rtn_wgrad_finish(h, dW, p.slab, S_used, (long long)d->N * Ktot, db, p.bslab, d->N, db ? db_n : 0, S_used * p.ncb, &fr);
 }

@@ -315,14 +315,22 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
     ([(13, 21)], 512, 512, 3, False),          # res5 branch2b: 32 output tiles, 8 splits
     ([(7, 250)], 64, 128, 1, True),            # image rows of 250 pixels: D = 4, the widest the LDS holds; one channel tile
     ([(3, 5), (64, 64)], 128, 256, 2, True),   # a tiny level first: its stages end inside the first split
+    ([(40, 334)], 64, 64, 2, False),           # res2 branch2b: the 64-filter form, D = 6 (160 KiB of LDS), one output tile
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 64, 4, "concat"),     # head output: dY padded to 64 columns, levels inside one tensor
+    ([(30, 40), (15, 20)], 128, 256, 2, "concat"),                           # the same layout on the 128-filter form
 ])
 def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bias):
     """csrc/rtn_wgrad_win.hip: weight (+ bias) gradient of the stride-1 3x3 layers with all nine taps in one output tile over a
     sliding window of the input.  Against float64 autograd on the bf16-rounded operands, against the general kernels
-    (RTN_WGRAD_WIN=0, RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (ordered slab sums)."""
+    (RTN_WGRAD_WIN=0, RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (ordered slab sums).
+    bias == "concat": the levels' dY lie one after another inside one [B, cells of all levels, cout] tensor (the head outputs)."""
     L = pkg._lib
     dtype = "bf16"
     tdt, code = DT[dtype]
+    concat = bias == "concat"
+    total = sum(H * W for H, W in levels)
+    dyfull = torch.zeros(B, total, cout, dtype=tdt, device=DEV) if concat else None
+    off = 0
     g = torch.Generator().manual_seed(900 + cin + cout)
     w = q(torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(9 * cin), dtype).requires_grad_(True)
     d = L.ConvDesc()
@@ -345,7 +353,12 @@ def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bia
         grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
         grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
         grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
-        grp.out, grp.out_elems, grp.out_img_stride = dyd.data_ptr(), dyd.numel(), H * W * cout
+        if concat:
+            dyfull[:, off:off + H * W, :] = dyd.reshape(B, H * W, cout)
+            grp.out, grp.out_elems, grp.out_img_stride, grp.out_off = dyfull.data_ptr(), dyfull.numel(), total * cout, off * cout
+            off += H * W
+        else:
+            grp.out, grp.out_elems, grp.out_img_stride = dyd.data_ptr(), dyd.numel(), H * W * cout
         d.g[gi] = grp
     wantm = want.permute(3, 0, 1, 2).reshape(cout, -1)
 

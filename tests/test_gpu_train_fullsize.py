@@ -127,13 +127,13 @@ EXPECTED_IMPLS = {
     ("dgrad", "res5b_branch2a"): 5, ("dgrad", "res5b_branch2b"): 2, ("dgrad", "res5b_branch2c"): 5,
     ("dgrad", "res2b_branch2b"): 2, ("dgrad", "res2b_branch2c"): 1, ("dgrad", "P6"): 2, ("dgrad", "P7"): 1,
     ("dgrad", "pyramid_regression"): 2, ("dgrad", "pyramid_classification"): 2,
-    # weight gradients: the nine-tap window kernel for the stride-1 3x3 layers with >= 128 channels (towers, P3, P4, res3-res5
-    # branch2b), the 256 x 256 LDS-DMA kernel for the 1x1 layers with >= 2048 pixel tiles (C3_reduced, res3a_branch1), the
+    # weight gradients: the nine-tap window kernel for the stride-1 3x3 layers (towers, P3, P4, res3-res5 branch2b; its 64-filter
+    # form for res2 branch2b and the head outputs), the 256 x 256 LDS-DMA kernel for the 1x1 layers with >= 2048 pixel tiles (C3_reduced, res3a_branch1), the
     # 128 x 128 LDS-DMA kernel for the rest
     ("wgrad", "pyramid_regression_0"): 4, ("wgrad", "pyramid_classification_3"): 4, ("wgrad", "P3"): 4, ("wgrad", "C3_reduced"): 2,
     ("wgrad", "res3a_branch1"): 2, ("wgrad", "P4"): 4, ("wgrad", "res3b_branch2b"): 4, ("wgrad", "res4b_branch2b"): 4,
-    ("wgrad", "res4f_branch2b"): 4, ("wgrad", "res5b_branch2b"): 4, ("wgrad", "res2b_branch2b"): 3, ("wgrad", "res4b_branch2a"): 3,
-    ("wgrad", "conv1"): 3, ("wgrad", "pyramid_regression"): 3, ("wgrad", "P6"): 3,
+    ("wgrad", "res4f_branch2b"): 4, ("wgrad", "res5b_branch2b"): 4, ("wgrad", "res2b_branch2b"): 4, ("wgrad", "res4b_branch2a"): 3,
+    ("wgrad", "conv1"): 3, ("wgrad", "pyramid_regression"): 4, ("wgrad", "P6"): 3,
 }
 
 

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, bench
 L = importlib.import_module(bench.PKG + "._lib")
 SHAPES = {"tower": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 256), "p3": ([(100, 167)], 256, 256),
-          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512), "p5": ([(25, 42)], 256, 256), "res4x2": ([(50, 84)], 256, 256)}
+          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512), "p5": ([(25, 42)], 256, 256), "res2": ([(200, 334)], 64, 64), "headout": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 64), "res4x2": ([(50, 84)], 256, 256)}
 name = sys.argv[1] if len(sys.argv) > 1 else "tower"
 variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_WGRAD_HALO=1", "RTN_WGRAD_HALO=0"])]
 levels, cin, cout = SHAPES[name]
