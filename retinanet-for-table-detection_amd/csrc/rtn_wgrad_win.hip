@@ -115,7 +115,7 @@ struct Cursor {
 };
 
 // EXP (timing experiments, wrong results): 1 = no staging in the loop, 2 = no fragment reads / MFMAs, 3 = neither
-template <int EXP, bool PS>
+template <int EXP, bool PS, bool STAGGER = true>
 __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWParams p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr unsigned WW_DYST = ww_dyst(PS), DY_ROW = PS ? 128u : 256u, DY_HALF = 32u * DY_ROW;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
 #pragma unroll
     for (int i = 0; i < WW_LA; ++i) issue_step();
     unsigned xc_ring = XRING, dyc_ring = 0;            // xc_ring: ring offset of the step's block + XRING (keeps the sums below non-negative)
-    const bool early = wave < 4;                       // the wave of each SIMD that stages right behind the barrier
+    const bool early = !STAGGER || wave < 4;           // the wave of each SIMD that stages right behind the barrier (STAGGER = false: both, measured 6.5 % slower)
 
     // one step: MUL = false for the load-only steps at the start of a run
     auto step = [&](auto mul_c) {
@@ -277,20 +277,21 @@ __global__ __launch_bounds__(WW_THREADS) void conv_wgrad_win_kernel(const WWPara
             for (int hs0 = 0; hs0 < (PS ? 1 : 2); ++hs0) {
                 const unsigned hs = PS ? (unsigned)wm : (unsigned)hs0;           // PS: the wave group's own half of the step
                 const unsigned xo = hs * 4096u, ao = dyc_ring + hs * DY_HALF;
-                s16x8 af[4], bf[3];
+                constexpr int ND = 2;                          // taps a B fragment is requested ahead of its MFMAs (3: no faster)
+                s16x8 af[4], bf[ND + 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i] = read_tr_at(ao + a_off[i], ao + a_off[i] + 4u * DY_ROW);
-                bf[0] = read_tr_at(xl[0] + xo, xl[0] + x_dl[0] + xo);
-                bf[1] = read_tr_at(xl[1] + xo, xl[1] + x_dl[1] + xo);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) bf[j] = read_tr_at(xl[j] + xo, xl[j] + x_dl[j] + xo);
                 if (bias_now)                          // BiasAddGrad on the matrix cores: dY^T x ones = the column sums of dY in every column
                     accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wk == 0 ? af[0] : wk == 1 ? af[1] : wk == 2 ? af[2] : af[3]),
                                                                    __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
-                    if (j + 2 < 9) bf[(j + 2) % 3] = read_tr_at(xl[j + 2] + xo, xl[j + 2] + x_dl[j + 2] + xo);
+                    if (j + ND < 9) bf[(j + ND) % (ND + 1)] = read_tr_at(xl[j + ND] + xo, xl[j + ND] + x_dl[j + ND] + xo);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j % 3]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j % (ND + 1)]), acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (PS && j == 3 && !(EXP & 1) && !early) issue_step();
                 }
@@ -460,7 +461,14 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
         hipLaunchKernelGGL((conv_wgrad_win_kernel<E_, PS_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);              \
     } while (0)
     const int dbg = rtn_env_int("RTN_WGRAD_WIN_DBG", 0);    // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
-    if (ps) {
+    if (!ps && rtn_env_int("RTN_WGRAD_WIN_STAGGER", 1) == 0) {       // A/B: every wave stages right behind the barrier
+        static bool attr_set = false;
+        if (!attr_set) {
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_wgrad_win_kernel<0, false, false>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);
+    } else if (ps) {
         if (dbg == 1) RTN_WW_LAUNCH(1, true); else if (dbg == 2) RTN_WW_LAUNCH(2, true); else if (dbg == 3) RTN_WW_LAUNCH(3, true); else RTN_WW_LAUNCH(0, true);
     } else {
         if (dbg == 1) RTN_WW_LAUNCH(1, false); else if (dbg == 2) RTN_WW_LAUNCH(2, false); else if (dbg == 3) RTN_WW_LAUNCH(3, false); else RTN_WW_LAUNCH(0, false);

@@ -5,17 +5,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, bench
 L = importlib.import_module(bench.PKG + "._lib")
 SHAPES = {"tower": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 256), "p3": ([(100, 167)], 256, 256),
-          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512), "p5": ([(25, 42)], 256, 256), "res2": ([(200, 334)], 64, 64), "headout": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 64), "res4x2": ([(50, 84)], 256, 256)}
+          "res4": ([(50, 84)], 256, 256), "res3": ([(100, 167)], 128, 128), "res5": ([(25, 42)], 512, 512), "p5": ([(25, 42)], 256, 256), "res2": ([(200, 334)], 64, 64), "headout": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 64), "res4x2": ([(50, 84)], 256, 256),
+          # 1x1 layers (cin, cout, k = 1)
+          "res4_2a": ([(50, 84)], 1024, 256, 1), "res4_2c": ([(50, 84)], 256, 1024, 1), "res3_2a": ([(100, 167)], 512, 128, 1),
+          "res3_2c": ([(100, 167)], 128, 512, 1), "res5_2a": ([(25, 42)], 2048, 512, 1), "res5_2c": ([(25, 42)], 512, 2048, 1),
+          "res2_2a": ([(200, 334)], 256, 64, 1), "res2_2c": ([(200, 334)], 64, 256, 1), "c3": ([(100, 167)], 512, 256, 1)}
 name = sys.argv[1] if len(sys.argv) > 1 else "tower"
 variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_WGRAD_HALO=1", "RTN_WGRAD_HALO=0"])]
-levels, cin, cout = SHAPES[name]
-B = bench.BATCH
+levels, cin, cout = SHAPES[name][:3]
+K = SHAPES[name][3] if len(SHAPES[name]) > 3 else 3
+B = int(os.environ.get("AB_BATCH", bench.BATCH))
 h = L.Handle(0)
 d = L.ConvDesc()
 d.ngroups, d.batch, d.dtype = len(levels), B, 0
-d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
+d.w_rows, d.N, d.KH, d.KW = cout, cout, K, K
 d.Crun = d.pix_stride = cin
-d.sy = d.sx = 1; d.pad_t = d.pad_l = 1; d.out_ld = cout
+d.sy = d.sx = 1; d.pad_t = d.pad_l = K // 2; d.out_ld = cout
 keep = []
 for gi, (H, W) in enumerate(levels):
     x = torch.randn(B, H, W, cin, device="cuda").to(torch.bfloat16); dy = torch.randn(B, H, W, cout, device="cuda").to(torch.bfloat16)
@@ -25,9 +30,9 @@ for gi, (H, W) in enumerate(levels):
     g.Hin, g.Win, g.Hout, g.Wout = H, W, H, W
     g.out, g.out_elems, g.out_img_stride = dy.data_ptr(), dy.numel(), H * W * cout
     d.g[gi] = g
-flops = 2.0 * sum(H * W for H, W in levels) * B * cout * 9 * cin
+flops = 2.0 * sum(H * W for H, W in levels) * B * cout * K * K * cin
 KNOBS = sorted({k for v in variants for k in v})
-dW = torch.zeros(cout, 9 * cin, device="cuda"); db = torch.zeros(cout, device="cuda")
+dW = torch.zeros(cout, K * K * cin, device="cuda"); db = torch.zeros(cout, device="cuda")
 times = {i: [] for i in range(len(variants))}
 for rnd in range(10):
     for i, v in enumerate(variants):
