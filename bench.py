@@ -211,7 +211,7 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
     value = world * B * steps / elapsed
     s = tr.norm_sums.cpu().numpy()
     achieved = value * TRAIN_GFLOP_PER_IMAGE / 1e3 / world
-    # dominant kernel of the training step: the head-tower weight gradients (8 launches of the 256 x 256 LDS-DMA kernel, the largest
+    # dominant kernel of the training step: the head-tower weight gradients (8 launches of the nine-tap window kernel, the largest
     # single share of the backward pass).  Measured live after the timed region: events on the launch stream around each launch,
     # launches one after another (untimed extra launches into the same gradient buffer, which the next step would zero anyway).
     dom = None
@@ -235,9 +235,11 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
             d0 = tower[0][1][1]
             fl = 2.0 * sum(d0.g[i].Hout * d0.g[i].Wout for i in range(d0.ngroups)) * B * d0.N * d0.KH * d0.KW * d0.Crun
             t_ms = sum(times) / len(times)
-            dom = {"kernel": "conv_wgrad_dma_kernel<4, 2, 8> + wgrad_finish_kernel (head-tower weight gradients: 3x3 256->256 over P3..P7, one grouped launch each)",
+            impl = int(L.lib.rtn_debug_last_wgrad_impl(eng.h.raw))
+            kname = {4: "conv_wgrad_win_kernel<0, false, true>", 2: "conv_wgrad_dma_kernel<4, 2, 8>", 1: "conv_wgrad_halo_kernel"}.get(impl, "conv_wgrad_kernel")
+            dom = {"kernel": kname + " + wgrad_finish_kernel (head-tower weight gradients: 3x3 256->256 over P3..P7, one grouped launch each)",
                    "launches_per_step": len(tower), "flop_per_launch": fl, "avg_launch_ms_solo": t_ms, "achieved_solo": fl / (t_ms * 1e-3) / 1e12,
-                   "frac_solo": fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "impl": int(L.lib.rtn_debug_last_wgrad_impl(eng.h.raw)),
+                   "frac_solo": fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "impl": impl,
                    "how": "events on the launch stream around 3 launches of each layer after the timed region (row-info table prebuilt, ordered slab reduction included)"}
     except Exception as e:              # the measurement beside the line may fail; the line itself may not
         dom = {"error": "%s: %s" % (type(e).__name__, e)}
