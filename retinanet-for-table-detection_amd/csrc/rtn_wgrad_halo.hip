@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ d
         const bool live = i < NK / 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
-            for (int s = s0; s < s1; ++s) {
+#pragma unroll 8
+            for (int s = s0; s < s1; ++s) {                               // (unrolled: the loads of eight splits in flight, the sums in the same order)
                 const float4 a = reinterpret_cast<const float4*>(slab + (size_t)s * NK)[i];
                 v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
             }
@@ -379,7 +380,7 @@ int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long l
         const long long bb = (nb + 256 / SL_ - 1) / (256 / SL_);                                                  \
         hipLaunchKernelGGL((wgrad_finish_kernel<SL_>), dim3((unsigned)(mb + bb)), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, nb, (int)mb, bS, fr); \
     } while (0)
-    if (S >= 64) RTN_WF(16); else if (S >= 8) RTN_WF(4); else RTN_WF(1);
+    if (S >= 64) RTN_WF(16); else if (S >= 16) RTN_WF(8); else if (S >= 8) RTN_WF(4); else RTN_WF(1);
 #undef RTN_WF
     RTN_CHECK_LAUNCH(h, "wgrad_finish_kernel");
     return RTN_OK;

@@ -318,6 +318,8 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
     ([(40, 334)], 64, 64, 2, False),           # res2 branch2b: the 64-filter form, D = 6 (160 KiB of LDS), one output tile
     ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 64, 4, "concat"),     # head output: dY padded to 64 columns, levels inside one tensor
     ([(30, 40), (15, 20)], 128, 256, 2, "concat"),                           # the same layout on the 128-filter form
+    ([(1, 7)], 64, 128, 40, True),             # one-row images: every slot's upper and lower neighbours are padding
+    ([(5, 1)], 128, 64, 48, True),             # one-column images (padded rows of 2 slots), 64-filter form
 ])
 def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bias):
     """csrc/rtn_wgrad_win.hip: weight (+ bias) gradient of the stride-1 3x3 layers with all nine taps in one output tile over a
