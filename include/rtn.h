@@ -142,7 +142,8 @@ size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
  * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel).  For tests and profiles: proves which native path executed. */
 int rtn_debug_last_conv_impl(rtn_handle_t h);
 /* Which weight-gradient kernel the last wgrad call of this handle ran: 1 the 3x3 halo kernel (csrc/rtn_wgrad_halo.hip), 2 the 256 x 256
- * LDS-DMA kernel, 3 the 128 x 128 LDS-DMA kernel, 0 the register-staged kernel (fp32 and odd shapes). */
+ * LDS-DMA kernel, 3 the 128 x 128 LDS-DMA kernel, 4 the nine-tap window kernel (csrc/rtn_wgrad_win.hip: stride-1 3x3 'same' layers
+ * with 64 or a multiple of 128 filters), 0 the register-staged kernel (fp32 and odd shapes). */
 int rtn_debug_last_wgrad_impl(rtn_handle_t h);
 int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d);
 
