@@ -99,6 +99,26 @@ def test_wgrad_workspace_sizes_without_gpu(pkg, monkeypatch):
     halo = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3))
     assert halo >= 16 * 256 * (9 * 256 + 1) * 4                     # 16 splits x ([N][9 C] + [N]) floats
     assert L.lib.rtn_conv2d_wgrad_workspace_bytes(None) == 0
+    # the nine-tap window kernel (csrc/rtn_wgrad_win.hip): S slabs of [N][9 C] accumulator fragments + S x (C / 64) bias parts of [N],
+    # S = 8 x 32 / output tiles; taken by work (RTN_WGRAD_WIN unset), wherever the shape allows (1), never (0)
+    monkeypatch.setenv("RTN_WGRAD_HALO", "0")
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
+    general = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3))
+    monkeypatch.setenv("RTN_WGRAD_WIN", "1")
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == 32 * 256 * (9 * 256 + 4) * 4 > general      # 8 output tiles, 32 splits
+    monkeypatch.delenv("RTN_WGRAD_WIN")
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == 32 * 256 * (9 * 256 + 4) * 4                # res4 branch2b is taken by default
+    d2 = desc(200, 334, 64, 64, 3)                                   # res2 branch2b: the 64-filter form, one output tile, 256 splits
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d2)) >= 256 * 64 * (9 * 64 + 1) * 4
+    small = desc(25, 42, 256, 256, 3)                                # P5: too little work for a chip-wide grid, stays on the general kernel
+    by_default = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(small))
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(small)) == by_default
+    wide = desc(8, 400, 128, 128, 3)                                 # image rows of 400 pixels: the ring does not fit the LDS, never taken
+    monkeypatch.setenv("RTN_WGRAD_WIN", "1")
+    forced = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(wide))
+    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(wide)) == forced
 
 
 def test_product_does_not_import_oracle():
