@@ -50,6 +50,8 @@ int rtn_env_int(const char* name, int dflt);
 void rtn_env_sync();
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
                        long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8 = nullptr);
+// rtn_conv_halo8r.hip: generation 4's tile with the filters loaded from a fragment-order copy (d->w_frag) straight into registers
+int rtn_conv_halo8r_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool forced, int mi_force);
 size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);
 struct rtn_wgrad_frag_t { int ncb, C, Ktot, wpt, co_tile; };   // slabs in the accumulator-fragment order of rtn_wgrad_win.hip (ncb > 0): waves per tile in the slab (8 / 4), filters per tile (128 / 64)
 int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n,
