@@ -424,6 +424,56 @@ def test_generation7_repeats_bit_for_bit(pkg, handle, monkeypatch):
                 assert torch.equal(a, b), "launch %d differs" % it
 
 
+@pytest.mark.parametrize("mi", [3, 4])
+@pytest.mark.parametrize("levels,cin,cout,relu,res,B,grid", [
+    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, True, None, 2, 0),   # head-tower shape: five levels, one grouped launch
+    ([(40, 67)], 256, 256, False, None, 3, 3),      # 32 tiles on 3 workgroups: every workgroup walks ~11 tiles (late reads at each tile start)
+    ([(25, 42), (13, 21)], 128, 200, True, None, 2, 1),   # two chunks per tap, N not a multiple of 16, ONE workgroup walks all tiles
+    ([(7, 300)], 256, 136, True, None, 1, 2),       # rows longer than a tile
+    ([(3, 5)], 256, 256, True, None, 1, 0),         # a single, mostly empty tile
+    ([(1, 40)], 64, 256, True, None, 2, 0),         # one chunk per tap: a group is three K steps
+    ([(40, 67)], 256, 256, False, "same", 2, 3),    # residual epilogue
+])
+def test_halo8_prefetching_step(pkg, handle, monkeypatch, levels, cin, cout, relu, res, B, grid, mi):
+    """RTN_CONV_H8_PF: generation 4 with the fragment reads of phase p + 1 issued inside phase p's MFMA block (second fragment set,
+    counted wait one phase earlier, four B pieces of step s + 2 per step).  Same products, same order: BIT FOR BIT the plain step."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "4")
+    monkeypatch.setenv("RTN_CONV_H8_KSPLIT", "1")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_H8_MI", str(mi))
+    flags = (L.CONV_RELU if relu else 0) | (L.CONV_RES_SAME if res else 0)
+    monkeypatch.setenv("RTN_CONV_H8_PF", "2")
+    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=40 + grid)
+    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
+    check(gots, wants, ld, n, "bf16")
+    monkeypatch.setenv("RTN_CONV_H8_PF", "0")
+    gots0, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=40 + grid, reference=False)
+    for a, b in zip(gots, gots0):
+        assert torch.equal(a, b), "prefetching and plain steps differ by %.3e" % float((a - b).abs().max())
+
+
+def test_halo8_prefetching_step_repeats_bit_for_bit(pkg, handle, monkeypatch):
+    """12 launches of a head-tower-sized layer with the prefetching step, both tile heights: the same bits every time (a fragment read
+    ahead of its stage's landing, or a stage rewritten under a read, would show as a tile that changes)."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "4")
+    monkeypatch.setenv("RTN_CONV_H8_PF", "2")
+    levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
+    first = None
+    for it in range(12):
+        monkeypatch.setenv("RTN_CONV_H8_MI", "3" if it < 8 else "4")
+        gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
+                                      reference=(it == 0))
+        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
+        if first is None:
+            check(gots, wants, ld, n, "bf16")
+            first = gots
+        else:
+            for a, b in zip(gots, first):
+                assert torch.equal(a, b), "launch %d differs" % it
+
+
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
     """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
