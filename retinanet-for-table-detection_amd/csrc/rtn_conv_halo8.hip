@@ -135,8 +135,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // B agree).  Block scales 2^0.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void mma_fp8(f32x4& acc, const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
-    const i32x8 A = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-    const i32x8 B = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    // a plain concatenation (REG_SEQUENCE): built element by element the compiler shuffled dwords through VALU moves in front of
+    // half of the MFMAs (v_pk_mov + s_nop 6 each)
+    const i32x8 A = __builtin_shufflevector(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 B = __builtin_shufflevector(__builtin_bit_cast(i32x4, b0), __builtin_bit_cast(i32x4, b1), 0, 1, 2, 3, 4, 5, 6, 7);
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
