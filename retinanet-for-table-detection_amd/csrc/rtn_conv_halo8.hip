@@ -806,7 +806,11 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                 bias_e[0] = b0.x; bias_e[1] = b0.y; bias_e[2] = b0.z; bias_e[3] = b0.w;
                 bias_e[4] = b1.x; bias_e[5] = b1.y; bias_e[6] = b1.z; bias_e[7] = b1.w;
             }
-            u32x4 rq[2][4], mq[2][4];               // residual / mask rows of fragment i (ping-pong: fragment i + 1 is in flight)
+            // residual / mask rows of the row fragments: with ONE of the two (the data gradients of the towers, P3, res4 branch2b take
+            // the mask only) every fragment's rows are requested before the first is used - one round trip per tile instead of one per
+            // fragment (the loop's fragment and address registers are dead here); with both, two fragments are in flight (ping-pong)
+            constexpr int EDEPTH = (EPI == 3 || (EPI == 1 && MI == 4)) ? 2 : MI;     // (residual only, 256 rows: four fragments in flight spill)
+            u32x4 rq[EDEPTH][4], mq[EDEPTH][4];
             auto fetch = [&](int i, int par) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -817,10 +821,13 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                     if (EPI & 2) mq[par][r] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, (int)(ok ? ((unsigned)m * (unsigned)p.mask_ld + (unsigned)ncol) * 2u : OOB), 0, 0);
                 }
             };
-            if (EPI) fetch(0, 0);
+            if (EPI) {
+#pragma unroll
+                for (int i = 0; i < EDEPTH - 1; ++i) fetch(i, i);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                if (EPI && i + 1 < MI) fetch(i + 1, (i + 1) & 1);
+                if (EPI && i + EDEPTH - 1 < MI) fetch(i + EDEPTH - 1, (i + EDEPTH - 1) % EDEPTH);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rloc = wm * (16 * MI) + i * 16 + kq * 4 + r;
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = acc[i][j][r] + (SPLIT ? bias_e[j] : 0.f);
                     if (EPI) {
-                        const u32x4 rw = rq[i & 1][r], mw = mq[i & 1][r];
+                        const u32x4 rw = rq[i % EDEPTH][r], mw = mq[i % EDEPTH][r];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const unsigned mj = (EPI & 2) ? mw[j] : 0x3f803f80u, rj = (EPI & 1) ? rw[j] : 0u;
