@@ -519,7 +519,9 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (tiles > 0x3fffffff) return 1;
     // too few tiles to be worth one workgroup per CU: below ~5/8 of the chip the 64-wide tiles of generation 2 (four times the
     // workgroups) win (res5 branch2a, 132 tiles: 0.049 ms here against 0.043; C5_reduced, 66 tiles: 0.046 against 0.041), above
-    // it this kernel does (res4 branch2a, 175 tiles: 0.037 against 0.046)
+    // it this kernel does (res4 branch2a, 175 tiles: 0.037 against 0.046).  (Round 3 re-measured: back-to-back launches of ONE layer
+    // say the opposite for res5 branch2a - 0.034 against 0.039 - because its 2 MB of filters then sit in the L2; in the step's own
+    // sequence, tools/profile_layers.py, it is 0.049 against 0.046-0.047 as before.  Judge such layers in sequence.)
     if (!forced && tiles * 8 < cus * 5) return 1;
     p.w = (const char*)d->w;
     p.bias = d->bias;
