@@ -405,14 +405,14 @@ def test_generation7_filters_in_registers(pkg, handle, monkeypatch, levels, cin,
 
 
 def test_generation7_repeats_bit_for_bit(pkg, handle, monkeypatch):
-    """12 launches of a head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) on generation 7 give the same
+    """6 launches of a head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) on generation 7 give the same
     bits at both tile heights: no halo piece lands after a fragment read, no weight fragment is multiplied before it arrived."""
     L = pkg._lib
     monkeypatch.setenv("RTN_CONV_IMPL", "7")
     levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
     first = None
-    for it in range(12):
-        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 8 else "3")
+    for it in range(6):
+        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 4 else "3")
         gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
                                       reference=(it == 0), frag=True)
         assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 7
@@ -454,15 +454,15 @@ def test_halo8_prefetching_step(pkg, handle, monkeypatch, levels, cin, cout, rel
 
 
 def test_halo8_prefetching_step_repeats_bit_for_bit(pkg, handle, monkeypatch):
-    """12 launches of a head-tower-sized layer with the prefetching step, both tile heights: the same bits every time (a fragment read
+    """6 launches of a head-tower-sized layer with the prefetching step, both tile heights: the same bits every time (a fragment read
     ahead of its stage's landing, or a stage rewritten under a read, would show as a tile that changes)."""
     L = pkg._lib
     monkeypatch.setenv("RTN_CONV_IMPL", "4")
     monkeypatch.setenv("RTN_CONV_H8_PF", "2")
     levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
     first = None
-    for it in range(12):
-        monkeypatch.setenv("RTN_CONV_H8_MI", "3" if it < 8 else "4")
+    for it in range(6):
+        monkeypatch.setenv("RTN_CONV_H8_MI", "3" if it < 4 else "4")
         gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
                                       reference=(it == 0))
         assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
