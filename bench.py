@@ -375,6 +375,9 @@ def main():
                    "launches_per_step": len(tower), "flop_per_launch": t_fl, "avg_launch_ms_solo": t_ms,
                    "achieved_solo": t_fl / (t_ms * 1e-3) / 1e12, "frac_solo": t_fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
                    "share_of_serial_conv_time": len(tower) * t_ms / serial_conv_ms,
+                   "bare_loop_ceiling": {"tflops": 1690.0, "what": "bf16 16x16x32 MFMAs + this kernel's fragment reads (6 ds_read_b128 per 16 MFMAs) "
+                                         "on random operands, no staging / barriers / epilogue; register-only loop 1992 TF/s at 1.97 GHz",
+                                         "source": "profiles/r3_micro_mfma_rate.txt (tools/micro/mfma_rate.hip, not measured in this run)"},
                    "how": "events on the launch stream around each launch, launches one after another, %d passes" % reps}
         ncand = int((plan["classification"] > 0.05).sum().item())
         def op_bytes(op):
