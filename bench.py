@@ -1,7 +1,8 @@
 """bench.py — images/sec of the RetinaNet R50-FPN detection path at 800x1333 on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-(N > 1 is launched by the driver with torch.distributed.run, one rank per GPU.)
+(N > 1: one rank per GPU.  Under torch.distributed.run (the driver's launch) each rank runs main(); run alone with --gpus N > 1 it
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process itself.  WORLD_SIZE != --gpus: exit 2.)
 
 Workload (BASELINE.json configs[1]): ResNet50-FPN RetinaNet INFERENCE, 800x1333, bf16, batch 8 per GPU:
 one step = stem pack -> ResNet-50 -> FPN -> both head stacks over P3..P7 -> decode + score threshold + NMS + top-k
@@ -279,10 +280,29 @@ def main():
                     help="infer (default, BASELINE.json configs[1]) or train (configs[2]/[3]: batch 16/GPU training step)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD torch.distributed.run (one rank per GPU) before this
+        # process has imported torch or touched the GPU, pass its output through (rank 0 prints the one JSON line) and return its
+        # exit code.  The child sees WORLD_SIZE and takes the branch below.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus "
+                         "(or run `python bench.py --gpus N` alone, which starts its own ranks)\n" % (args.gpus, world))
+        sys.exit(2)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
