@@ -237,7 +237,7 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
             fl = 2.0 * sum(d0.g[i].Hout * d0.g[i].Wout for i in range(d0.ngroups)) * B * d0.N * d0.KH * d0.KW * d0.Crun
             t_ms = sum(times) / len(times)
             impl = int(L.lib.rtn_debug_last_wgrad_impl(eng.h.raw))
-            kname = {4: "conv_wgrad_win_kernel<0, false, true>", 2: "conv_wgrad_dma_kernel<4, 2, 8>", 1: "conv_wgrad_halo_kernel"}.get(impl, "conv_wgrad_kernel")
+            kname = {4: "conv_wgrad_win_kernel<0, false, true>", 2: "conv_wgrad_dma_kernel<4, 2, 8>"}.get(impl, "conv_wgrad_kernel")
             dom = {"kernel": kname + " + wgrad_finish_kernel (head-tower weight gradients: 3x3 256->256 over P3..P7, one grouped launch each)",
                    "launches_per_step": len(tower), "flop_per_launch": fl, "avg_launch_ms_solo": t_ms, "achieved_solo": fl / (t_ms * 1e-3) / 1e12,
                    "frac_solo": fl / (t_ms * 1e-3) / 1e12 / BF16_DENSE_PEAK_TFLOPS, "impl": impl,

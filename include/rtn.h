@@ -133,25 +133,15 @@ typedef struct {
                                 streams) need different buffers.  NULL / too small = no K split for this launch (slower on
                                 the few layers that want one, same results up to f32 summation order).  */
     int64_t workspace_bytes;
-    const void* w_frag;      /* optional (NULL = none): the SAME filters in MFMA-fragment order, written by rtn_pack_frag_weights
-                                from `w`.  With it the stride-1 3x3 bf16 layers with 129..256 output channels (head towers, P3, P4,
-                                res4 branch2b; their data gradients) run on the seventh kernel generation, which reads its filters
-                                straight into registers (csrc/rtn_conv_halo8r.hip); bit-identical results.  The caller refreshes it
-                                whenever `w` changes.  */
 } rtn_conv_desc_t;
 
 /* Bytes of `workspace` the launch described by `d` can use on this device (0 for most layers).  The library never allocates:
  * every forward / dgrad entry point below takes its scratch from the descriptor. */
 size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
 /* Which kernel generation the last convolution launch on this handle ran (1: 128-row register-staged, 2: 256-row LDS-DMA per tap,
- * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel, 7: generation 4's tile with the filters read straight into registers).  For tests and profiles: proves which native path executed. */
+ * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel).  For tests and profiles: proves which native path executed. */
 int rtn_debug_last_conv_impl(rtn_handle_t h);
-/* Fragment-order copy of bf16 filters w[w_rows >= N][Ktot] (K contiguous, N <= 256, Ktot % 64 == 0) for rtn_conv_desc_t.w_frag:
- * 256 * Ktot elements at `wf`; 16-byte unit ((((kb*2 + h)*4 + wn)*4 + jw)*64 + 16*kq + rho) holds filter
- * 64*wn + 16*(rho>>2) + 4*jw + (rho&3), K elements [64*kb + 32*h + 8*kq, +8); filters >= w_rows are zeros.  The generation-7 kernel
- * then loads a 16x32 MFMA operand of the filters of model/defineModel.py:101-117,155-163,183-203 with ONE coalesced 1-KiB read. */
-int rtn_pack_frag_weights(rtn_handle_t h, const void* w, void* wf, int w_rows, int N, int64_t Ktot);
-/* Which weight-gradient kernel the last wgrad call of this handle ran: 1 the 3x3 halo kernel (csrc/rtn_wgrad_halo.hip), 2 the 256 x 256
+/* Which weight-gradient kernel the last wgrad call of this handle ran: 2 the 256 x 256
  * LDS-DMA kernel, 3 the 128 x 128 LDS-DMA kernel, 4 the nine-tap window kernel (csrc/rtn_wgrad_win.hip: stride-1 3x3 'same' layers
  * with 64 or a multiple of 128 filters), 0 the register-staged kernel (fp32 and odd shapes). */
 int rtn_debug_last_wgrad_impl(rtn_handle_t h);

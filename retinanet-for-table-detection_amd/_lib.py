@@ -52,7 +52,6 @@ class ConvDesc(C.Structure):
         ("Crun", C.c_int32), ("pix_stride", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
         ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("out_ld", C.c_int32), ("flags", C.c_int32),
         ("reserved_", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-        ("w_frag", C.c_void_p),
     ]
 
 
@@ -105,7 +104,6 @@ SIGNATURES = {
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
-    "rtn_pack_frag_weights": (_I, [_P, _P, _P, _I, _I, _I64]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_pack_dgrad_weights_multi": (_I, [_P, _P, _I, _I64, _I]),
     "rtn_conv2d_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvDesc)]),

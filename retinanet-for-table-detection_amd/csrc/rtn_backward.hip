@@ -528,212 +528,75 @@ __global__ __launch_bounds__(64 * NWN * NWK, 2) void conv_wgrad_dma_kernel(const
         }
 }
 
-// ------------------------------------------------------------------------------------------------ 256 x 256, LDS-DMA RING (bf16)
-// conv_wgrad_dma_kernel<4, 2, 8> stages one 64-pixel step ahead and ends every step with vmcnt(0) + barrier: the whole LDS-DMA
-// latency of 64 KB per CU (all 256 CUs bursting together) stands between two steps, and the loop runs at 3.0 us per 64 pixels for
-// 0.86 us of MFMA work (head-tower layer: 0.29 ms, 0.29 of peak, twice the forward kernel).  Same tile, same LDS image, same
-// fragment reads here, but the pixel stream is cut into 32-pixel stages (one 16x16x32 MFMA slab) in a RING OF FOUR: the stage
-// multiplied in iteration i was requested in iteration i - 3, the one counted wait per iteration (vmcnt(8): everything but the two
-// youngest stages) never waits for a request younger than two iterations.  vmcnt retires in order, so the per-pixel row info (16 B:
-// tap-(0,0) offset, dY offset, iy0 | ix0) may not come through vector loads (a wait for it would drain the DMAs issued before it):
-// the four rows a wave stages per piece pair are wave-uniform and adjacent, and come in through two s_load_dwordx8 (lgkmcnt).
-// Past the end of the split the DMAs are still issued, out of range (zeros into a ring slot nobody reads), so the count is fixed.
-typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+// (A ring-of-four variant of the 256 x 256 kernel - 32-pixel stages, one counted wait per iteration, row info through scalar loads -
+// was built in round 3, bit-identical and 1-16 % slower on every layer (profiles/r3_wgrad_ring_ab.txt, r3_wgrad_ring128_ab.txt: the loop
+// is bound by instruction issue, not by the latency its vmcnt(0) exposes); removed in round 4.)
 
-__device__ __forceinline__ u32x8 wr_sload8(const void* base, unsigned byte_off) {
-    u32x8 v;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "s"(byte_off) : "memory");
-    return v;
-}
-
-template <bool STAGGER>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_ring_kernel(const WParams p) {
-    constexpr int NW = 8, NWK = 2, FJ = 8, TS = 256;
-    constexpr int WD_ROWB = TS * 2;               // 512 bytes per pixel row of an operand tile
-    constexpr int PX = 32;                        // pixels per stage
-    constexpr int OP_B = PX * WD_ROWB;            // 16 KB per operand and stage
-    constexpr int NST = 4;
-    constexpr int CPR = WD_ROWB / 16;             // 32 chunks per row
-    __shared__ __attribute__((aligned(16))) char lds[NST * 2 * OP_B];   // [stage][dY | X] = 128 KB
-
-    int otile, split;
-    if (p.xcd_map) {
-        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        const int sl = j / p.out_tiles;
-        otile = j - sl * p.out_tiles;
-        split = sl * 8 + xcd;
-    } else {
-        otile = blockIdx.x;
-        split = blockIdx.y;
-    }
-    const int tile_n = otile / p.ntiles_k;
-    const int tile_k = otile - tile_n * p.ntiles_k;
-    const int n0 = tile_n * TS, k0 = tile_k * TS;
-    const int tlo = split * p.tiles_per_split;
-    int thi = tlo + p.tiles_per_split;
-    thi = thi < p.total_tiles ? thi : p.total_tiles;
-    if (tlo >= thi) return;
-    const int hlo = 2 * tlo, hhi = 2 * thi;       // 32-pixel half tiles
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // ---- staging role: piece i (0, 1) of this wave = rows 2 wave + 16 i + (lane >> 5), LDS chunk position lane & 31
-    const int rsub = lane >> 5;
-    const int srow0 = 2 * wave + rsub;
-    const int skey = (srow0 & 3) | (((srow0 >> 3) & 1) << 2);  // the same for both pieces (+16 keeps row & 3 and bit 3)
-    const int sc = (lane & (CPR - 1)) ^ (skey << 1);           // source chunk (8 elements) this lane fetches
-    const int kk = k0 + sc * 8;
-    const bool kvalid = kk < p.Ktot;
-    const int kpos = kk >> p.cshift;
-    const int coff = kk & p.crun_mask;
-    const int kh = (kpos * p.kw_inv) >> 16;
-    const int kw = kpos - kh * p.KW;
-    const int nn = n0 + sc * 8;
-    const bool nvalid = nn < p.N;
-    const unsigned dyo = (unsigned)(nn * 2);
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-
-    const int wm = wave / NWK, wn = wave % NWK;
-    f32x4 acc[4][FJ];
+// ------------------------------------------------------------------------------------------------ ordered reduction of the pixel splits
+// dW[i] += slab[0][i] + slab[1][i] + ... + slab[S-1][i] with a FIXED association: the S splits are cut into SL consecutive ranges, every
+// range is summed in order by one "split lane" (SL lanes x 256 / SL float4 columns per block), and the SL partial sums are added in
+// lane order.  Same bits on every run; SL only spreads the loads of a many-split, few-weights layer (res2: 256 splits x 16 K weights)
+// over enough threads.  Blocks past `main_blocks` do the same for the bias slabs (scalar columns).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dW, const float* __restrict__ slab, int S, long long NK,
+                                                           float* __restrict__ db, const float* __restrict__ bslab, int N, int db_n, int main_blocks,
+                                                           int bS, rtn_wgrad_frag_t fr) {
+    constexpr int CB = 256 / SL;
+    __shared__ float4 part[SL][CB];
+    const int c = threadIdx.x % CB, sl = threadIdx.x / CB;
+    const bool is_main = (int)blockIdx.x < main_blocks;
+    const int Sx = is_main ? S : bS;                      // the bias slabs may come in a different number of parts (rtn_wgrad_win.hip)
+    const int per = (Sx + SL - 1) / SL;
+    const int s0 = sl * per < Sx ? sl * per : Sx, s1 = s0 + per < Sx ? s0 + per : Sx;
+    if (is_main) {
+        const long long i = (long long)blockIdx.x * CB + c;          // float4 column
+        const bool live = i < NK / 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live)
+#pragma unroll 8
+            for (int s = s0; s < s1; ++s) {                               // (unrolled: the loads of eight splits in flight, the sums in the same order)
+                const float4 a = reinterpret_cast<const float4*>(slab + (size_t)s * NK)[i];
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+        part[sl][c] = v;
+        __syncthreads();
+        if (sl == 0 && live) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = p.db != nullptr && tile_k == 0 && wn == 0;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-    // row info of half tile H, piece i: rows H * 32 + 2 wave + 16 i and the next one (32 bytes, wave-uniform)
-    auto ri_load = [&](int H, int i) -> u32x8 {
-        const int Hc = H < hhi ? H : hhi - 1;
-        return wr_sload8(p.rowinfo, (unsigned)((Hc * 32 + 2 * wave + 16 * i) * 16));
-    };
-    auto stage = [&](int H, int slot, const u32x8& r0, const u32x8& r1) {
-        const bool live = H < hhi;
-        int gi_ = 0;
-#pragma unroll
-        for (int i_ = 1; i_ < RTN_MAX_GROUPS; ++i_)
-            if (i_ < p.ngroups && (H >> 1) >= p.g[i_].tile_begin) gi_ = i_;
-        const WGroup& G_ = p.g[live ? gi_ : 0];
-        const i32x4 xs_ = wd_make_srd(G_.x, G_.x_bytes);
-        const i32x4 ys_ = wd_make_srd(G_.dy, G_.dy_bytes);
-        const unsigned delta_ = (unsigned)(kh * G_.x_row_stride_b + kw * p.pix_stride_b + coff * 2);
-        const int Hin_ = G_.Hin, Win_ = G_.Win;
-#pragma unroll
-        for (int i_ = 0; i_ < 2; ++i_) {
-            const u32x8& r = i_ ? r1 : r0;
-            const unsigned rx = rsub ? r[4] : r[0], ry = rsub ? r[5] : r[1], rz = rsub ? r[6] : r[2];
-            const int iy_ = (int)(short)(rz & 0xffffu) + kh, ix_ = (int)(short)(rz >> 16) + kw;
-            const bool ok_ = live && kvalid && (unsigned)iy_ < (unsigned)Hin_ && (unsigned)ix_ < (unsigned)Win_;
-            const unsigned piece_ = (unsigned)((wave + NW * i_) * 1024);
-            wd_dma16(ys_, (live && nvalid && ry != OOB_OFFSET) ? ry + dyo : OOB_OFFSET, lds_base + (unsigned)(slot * 2 * OP_B) + piece_);
-            wd_dma16(xs_, ok_ ? rx + delta_ : OOB_OFFSET, lds_base + (unsigned)(slot * 2 * OP_B + OP_B) + piece_);
-        }
-    };
-#define WR_RI_WAIT(A, B) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) :: "memory")
-
-    // ---- prologue: stages 0..2 requested, the row info of stage 3 on its way
-    u32x8 ra = ri_load(hlo, 0), rb = ri_load(hlo, 1);
-    WR_RI_WAIT(ra, rb);
-    stage(hlo, 0, ra, rb);
-    ra = ri_load(hlo + 1, 0); rb = ri_load(hlo + 1, 1);
-    WR_RI_WAIT(ra, rb);
-    stage(hlo + 1, 1, ra, rb);
-    ra = ri_load(hlo + 2, 0); rb = ri_load(hlo + 2, 1);
-    WR_RI_WAIT(ra, rb);
-    stage(hlo + 2, 2, ra, rb);
-    ra = ri_load(hlo + 3, 0); rb = ri_load(hlo + 3, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // stage 0 has landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const int rkey = q | ((g & 1) << 2);
-    const int row = 8 * g + q;
-    // Two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run ONE BARRIER APART, as in rtn_conv_halo8.hip: an iteration is
-    // {R: request stage H + 3, read all fragments of stage H | barrier | M: 32 MFMAs | barrier}, so while one wave of a SIMD
-    // multiplies the other issues its LDS-DMA pieces and fragment reads.  The counted wait sits at the END of R: a wave's pieces of
-    // stage H + 1 have landed one barrier before the other group's (two before its own) reads of that stage; all fragment reads have
-    // returned before the barrier that ends R, two intervals before any wave requests the stage that overwrites their slot.
-    const int grp = wave >> 2;
-    if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-    for (int H = hlo; H < hhi; ++H) {
-        const int cur = (H - hlo) & 3;
-        const char* A = lds + cur * 2 * OP_B;          // dY stage
-        const char* B = A + OP_B;                      // X stage
-        // ---- R: the row info requested one iteration ago is here: request stage H + 3 into the slot stage H - 1 was read from
-        WR_RI_WAIT(ra, rb);
-        stage(H + 3, (cur + 3) & 3, ra, rb);
-        ra = ri_load(H + 4, 0); rb = ri_load(H + 4, 1);
-        s16x8 af[4], bf[FJ];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ca = (wm * 64 + 16 * i + 4 * pp) * 2;            // byte column inside the 512-byte row
-            const int aoff = row * WD_ROWB + (((ca >> 5) ^ rkey) << 5) + (ca & 31);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(A + aoff + 4 * WD_ROWB));
-            af[i] = (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            const int cb = (wn * 16 * FJ + 16 * j + 4 * pp) * 2;
-            const int boff = row * WD_ROWB + (((cb >> 5) ^ rkey) << 5) + (cb & 31);
-            const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff));
-            const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(B + boff + 4 * WD_ROWB));
-            bf[j] = (s16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
-        }
-        // stage H + 1 has landed (H + 2, H + 3 stay in flight); every fragment read above has returned (the scalar row-info loads too)
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : "+s"(ra), "+s"(rb) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- M
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < FJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                    __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (do_bias) {                              // BiasAddGrad: the A fragment of lane (m, kq) holds 8 pixels of channel m
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[i] += __uint_as_float(((unsigned)(unsigned short)af[i][e]) << 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();
-#undef WR_RI_WAIT
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may land in LDS (or in SGPRs) after the loop
-
-    const int lr = (lane >> 4) * 4, lc = lane & 15;
-    if (do_bias) {       // lane (m = lane & 15, kq = lane >> 4): fold the four pixel groups, lanes 0..15 add channel m
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = bsum[i];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int n = n0 + wm * 64 + 16 * i + lc;
-            if (lane < 16 && n < p.db_n) { if (p.slab) p.bslab[(long long)split * p.N + n] = v; else unsafeAtomicAdd(p.db + n, v); }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            const int kc = k0 + wn * 16 * FJ + 16 * j + lc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * 64 + 16 * i + lr + r;
-                if (n < p.N && kc < p.Ktot) {
-                    if (p.slab) p.slab[((long long)split * p.N + n) * p.Ktot + kc] = acc[i][j][r];
-                    else unsafeAtomicAdd(p.dW + (long long)n * p.Ktot + kc, acc[i][j][r]);
-                }
+            for (int l = 1; l < SL; ++l) { const float4 a = part[l][c]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            if (fr.ncb > 0) {
+                // slabs in accumulator-fragment order (rtn_wgrad_win.hip): float4 i = [tile][wave][tap j][i4][lane] holds rows
+                // n .. n + 3 of ONE column: n = co_tile tn + 64 wm + 16 i4 + 4 (lane / 16), k = j C + 64 cb + 16 wk + lane % 16
+                const int lane = (int)(i & 63);
+                const unsigned f = (unsigned)(i >> 6);                  // NK < 2^32
+                const int i4 = (int)(f & 3);
+                const unsigned t2 = f >> 2, t3 = t2 / 9u;
+                const int j = (int)(t2 - t3 * 9u);
+                const int tile = (int)(t3 / (unsigned)fr.wpt), wave = (int)t3 - tile * fr.wpt;
+                const int tn = tile / fr.ncb, cb = tile - tn * fr.ncb;
+                const int n = fr.co_tile * tn + 64 * (wave >> 2) + 16 * i4 + 4 * (lane >> 4);
+                const int k = j * fr.C + 64 * cb + 16 * (wave & 3) + (lane & 15);
+                float* o = dW + (size_t)n * fr.Ktot + k;
+                o[0] += v.x; o[fr.Ktot] += v.y; o[2 * (size_t)fr.Ktot] += v.z; o[3 * (size_t)fr.Ktot] += v.w;
+            } else {
+                float4 w = reinterpret_cast<float4*>(dW)[i];
+                w.x += v.x; w.y += v.y; w.z += v.z; w.w += v.w;
+                reinterpret_cast<float4*>(dW)[i] = w;
             }
         }
+    } else {
+        const int n = ((int)blockIdx.x - main_blocks) * CB + c;
+        const bool live = n < db_n;
+        float v = 0.f;
+        if (live)
+            for (int s = s0; s < s1; ++s) v += bslab[(size_t)s * N + n];
+        part[sl][c].x = v;
+        __syncthreads();
+        if (sl == 0 && live) {
+#pragma unroll
+            for (int l = 1; l < SL; ++l) v += part[l][c].x;
+            db[n] += v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
@@ -1296,15 +1159,28 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     return w;
 }
 
-// rtn_wgrad_halo.hip (stride-1 3x3 layers with whole 128-channel blocks) against the general kernels, measured per shape at batch 8
-// (tools/ab_wgrad.py): res4 branch2b / P4 0.075 vs 0.110 ms, res3 branch2b 0.067 vs 0.082, but head towers 0.302 vs 0.284, P3 0.230 vs
-// 0.230, res5 branch2b 0.091 vs 0.086.  So it takes the layers the 256 x 256 LDS-DMA kernel does not, from ~25 k pixels on.
-// RTN_WGRAD_HALO=1: wherever the shape allows (tests, A/B), 0: never.
-static bool wgrad_takes_halo(const rtn_conv_desc_t* d, const WgradPlan& w) {
-    const int knob = rtn_env_int("RTN_WGRAD_HALO", -1);
-    if (knob == 0 || rtn_wgrad_halo_workspace_bytes(d) == 0) return false;
-    if (knob > 0) return true;
-    return !w.dma && w.tiles >= 400;
+// (rtn_wgrad_halo.hip, the one-kernel-row-per-tile 3x3 kernel of round 2, lost every layer of the benchmark shapes to the window
+// kernel below and left the library in round 4: profiles/r2_v3_ab_wgrad_halo.txt, r3_wgrad_win_ab.txt.)
+
+// dW[0..NK) += slab[0] + slab[1] + ... + slab[S-1] (in that order), db[0..db_n) likewise from bslab[S][N]: the ordered reduction
+// of the pixel splits of every weight-gradient kernel
+int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n, int bS,
+                     const rtn_wgrad_frag_t* frag) {
+    if (!dW || !slab || S < 1 || NK < 4 || NK % 4) return rtn_fail(h, RTN_EINVAL, "wgrad finish: bad argument");
+    const int nb = db ? db_n : 0;
+    if (bS < 1) bS = S;
+    rtn_wgrad_frag_t fr = {0, 0, 0, 8, 128};
+    if (frag) fr = *frag;
+#define RTN_WF(SL_)                                                                                               \
+    do {                                                                                                          \
+        const long long mb = (NK / 4 + 256 / SL_ - 1) / (256 / SL_);                                              \
+        const long long bb = (nb + 256 / SL_ - 1) / (256 / SL_);                                                  \
+        hipLaunchKernelGGL((wgrad_finish_kernel<SL_>), dim3((unsigned)(mb + bb)), dim3(256), 0, h->stream, dW, slab, S, NK, db, bslab, N, nb, (int)mb, bS, fr); \
+    } while (0)
+    if (S >= 64) RTN_WF(16); else if (S >= 16) RTN_WF(8); else if (S >= 8) RTN_WF(4); else RTN_WF(1);
+#undef RTN_WF
+    RTN_CHECK_LAUNCH(h, "wgrad_finish_kernel");
+    return RTN_OK;
 }
 
 // rtn_wgrad_win.hip (all nine taps per output tile over a sliding window of the input; stride-1 3x3 layers with whole blocks of 128
@@ -1321,20 +1197,21 @@ static bool wgrad_takes_win(const rtn_conv_desc_t* d, const WgradPlan& w) {
     return w.tiles * (long long)(d->N == 64 ? 1 : 2 * (d->N / 128)) * (d->Crun / 64) >= 6000;
 }
 
-// workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the 3x3 halo kernel
-// (rtn_wgrad_halo.hip) uses the same bytes for its own slabs
+// workspace = the row-info table, then (unless RTN_WGRAD_SLAB=0) the per-split slabs of the ordered reduction; the nine-tap window
+// kernel (rtn_wgrad_win.hip) uses the same bytes for its own slabs
 extern "C" size_t rtn_conv2d_wgrad_workspace_bytes(const rtn_conv_desc_t* d) {
     rtn_env_sync();
     if (!d || d->ngroups < 1 || d->ngroups > RTN_MAX_GROUPS || d->N < 1 || d->Crun < 1 || d->KH < 1 || d->KW < 1) return 0;
     if (d->dtype != RTN_BF16 && d->dtype != RTN_F32) return 0;
     const WgradPlan w = wgrad_plan(d, 256);
-    size_t table = ((size_t)w.tiles * 64 * sizeof(uint4) + 255) & ~(size_t)255;
+    const size_t table = ((size_t)w.tiles * 64 * sizeof(uint4) + 255) & ~(size_t)255;
+    size_t slabs = 0;
     if (rtn_env_int("RTN_WGRAD_SLAB", 1) != 0)
-        table += (size_t)w.nsplit_used * (size_t)d->N * ((size_t)d->KH * d->KW * d->Crun + 1) * sizeof(float);
-    const size_t halo = wgrad_takes_halo(d, w) ? rtn_wgrad_halo_workspace_bytes(d) : 0;
+        slabs = (size_t)w.nsplit_used * (size_t)d->N * ((size_t)d->KH * d->KW * d->Crun + 1) * sizeof(float);
+    // the window kernel's slabs also sit BEHIND the table (16 B per pixel): a table built once by rtn_conv2d_wgrad_rowinfo stays valid
+    // whichever kernel later prepared calls select
     const size_t win = wgrad_takes_win(d, w) ? rtn_wgrad_win_workspace_bytes(d) : 0;
-    const size_t special = halo > win ? halo : win;
-    return table > special ? table : special;
+    return table + (slabs > win ? slabs : win);
 }
 
 static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes,
@@ -1386,9 +1263,10 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
         if (workspace_bytes < need) return rtn_fail(h, RTN_ENOMEM, "wgrad: workspace %zu < %zu", workspace_bytes, need);
     }
 
-    const bool take_win = wgrad_takes_win(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256));
-    // the stride-1 3x3 layers with whole 128-channel blocks that rtn_wgrad_halo.hip runs faster (wgrad_takes_halo)
-    if (take_win || wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
+    // the stride-1 3x3 layers the nine-tap window kernel takes (wgrad_takes_win).  Mode 1 (table only) never stops here: the row-info
+    // table is built for every layer, so that a later prepared call that selects the general kernels (a knob flipped in between, a
+    // shape the window kernel turns down) never runs on an unprepared table.
+    if (mode != 1 && wgrad_takes_win(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
         bool ok = true;
         for (int i = 0; i < d->ngroups && ok; ++i) {
             const rtn_conv_group_t& s = d->g[i];
@@ -1396,18 +1274,13 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
             ok = s.in && s.out && !((uintptr_t)s.in & 15) && !((uintptr_t)s.out & 15) && s.in_elems >= M * d->Crun &&
                  s.out_elems >= (M - 1) * d->out_ld + d->N;
         }
-        if (ok) {
-            if (mode == 1) return RTN_OK;              // nothing to prepare
-            if (take_win) {
-                const int rc = rtn_wgrad_win_try(h, d, dW, db, db_n, workspace, workspace_bytes);
-                if (rc == RTN_OK) h->last_wgrad_impl = 4;
-                if (rc <= 0) return rc;
-            }
-            if (wgrad_takes_halo(d, wgrad_plan(d, h->num_cus > 0 ? h->num_cus : 256))) {
-                const int rc = rtn_wgrad_halo_try(h, d, dW, db, db_n, workspace, workspace_bytes);
-                if (rc == RTN_OK) h->last_wgrad_impl = 1;
-                if (rc <= 0) return rc;
-            }
+        long long t64 = 0;
+        for (int i = 0; i < d->ngroups; ++i) t64 += ((long long)d->g[i].Hout * d->g[i].Wout * d->batch + 63) / 64;
+        const size_t table_b = ((size_t)t64 * 64 * sizeof(uint4) + 255) & ~(size_t)255;       // its slabs start behind the row-info table
+        if (ok && workspace_bytes > table_b) {
+            const int rc = rtn_wgrad_win_try(h, d, dW, db, db_n, (char*)workspace + table_b, workspace_bytes - table_b);
+            if (rc == RTN_OK) h->last_wgrad_impl = 4;
+            if (rc <= 0) return rc;
         }
     }
 
@@ -1482,11 +1355,7 @@ static int wgrad_launch(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, flo
     p.out_tiles = (int)out_tiles;
     p.xcd_map = xcd_map ? 1 : 0;
     dim3 grid = xcd_map ? dim3((unsigned)(out_tiles * nsplit)) : dim3((unsigned)out_tiles, (unsigned)nsplit);
-    // the ring kernel reads the row-info table through 32-bit scalar offsets: tables beyond 4 GiB stay on the two-stage kernel
-    const bool ring = dma && rtn_env_int("RTN_WGRAD_RING", 0) != 0 && (long long)tiles * 64 * 16 < (1ll << 32);
-    if (ring && rtn_env_int("RTN_WGRAD_RING_STAGGER", 1) != 0) hipLaunchKernelGGL(conv_wgrad_ring_kernel<true>, grid, dim3(512), 0, h->stream, p);
-    else if (ring)      hipLaunchKernelGGL(conv_wgrad_ring_kernel<false>, grid, dim3(512), 0, h->stream, p);
-    else if (dma)       hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
+    if (dma)            hipLaunchKernelGGL((conv_wgrad_dma_kernel<4, 2, 8>), grid, dim3(512), 0, h->stream, p);
     else if (dma_small) hipLaunchKernelGGL((conv_wgrad_dma_kernel<2, 2, 4>), grid, dim3(256), 0, h->stream, p);
     else if (es == 2) hipLaunchKernelGGL((conv_wgrad_kernel<2>), grid, dim3(256), 0, h->stream, p);
     else              hipLaunchKernelGGL((conv_wgrad_kernel<4>), grid, dim3(256), 0, h->stream, p);

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
 // instead of issuing them ahead of the MFMA block (measured slower: 1084 vs 1226 TF/s on the head layers).
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
-    return (v >= 1 && v <= 7) ? v : 0;                 // 4 / 5 / 6 / 7 = the persistent kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip / rtn_conv_halon.hip / rtn_conv_halo8r.hip) where they apply
+    return (v >= 1 && v <= 6) ? v : 0;                 // 4 / 5 / 6 = the persistent kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip / rtn_conv_halon.hip) where they apply
 }
 
 int ilog2_exact(int v) {
@@ -1450,20 +1450,6 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     // P4 0.062 -> 0.047.  RTN_CONV_H8=0 turns it off (A/B), RTN_CONV_IMPL=4 forces it like any other generation;
     // RTN_CONV_H8_GRID limits the workgroup count (tests: several tiles per workgroup on small layers), RTN_CONV_H8_STAGGER=0 runs
     // the two wave groups in lockstep (A/B: 0.181 ms on the head layer).
-    // Seventh generation (rtn_conv_halo8r.hip): generation 4's layers when the caller supplies the filters in fragment order
-    // (d->w_frag) and the grid fills at least half the chip; no workspace.  Bit-identical to generation 4 and measured SLOWER
-    // (head-tower layer 0.168 against 0.143 ms, profiles/r3_gen7_filters_in_registers.txt), so it is OFF unless RTN_CONV_H8R=1 or
-    // RTN_CONV_IMPL=7 ask for it.
-    if (!s2 && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16 && d->w_frag) {
-        const int forced = rtn_conv_impl_override();
-        if (forced == 7 || (forced == 0 && rtn_env_int("RTN_CONV_H8R", 0) != 0)) {
-            if (!query) {                              // it needs no workspace: a query falls through to what generation 4 would ask for
-                const int rc = rtn_conv_halo8r_try(h, d, rtn_env_int("RTN_CONV_H8_GRID", 0), forced == 7, rtn_env_int("RTN_CONV_H8_MI", 0));
-                if (rc == RTN_OK) h->last_conv_impl = 7;
-                if (rc <= 0) return rc;
-            }
-        }
-    }
     if (!s2 && out8_scale == 0.f && (q8 ? d->dtype == RTN_FP8 && !query : d->dtype == RTN_BF16)) {
         const int h8 = rtn_env_int("RTN_CONV_H8", 1);
         const int forced = rtn_conv_impl_override();

@@ -159,25 +159,11 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // reads-per-MFMA ratio as the wide tile), the B stage has two 64-row pieces, a lane ends up with 4 consecutive channels (8-byte stores).
 // ES: bytes per element.  2 = bf16.  1 = fp8 e4m3 (rtn_conv2d_fp8_fwd): the same LDS bytes (a 128-byte row is 128 K positions), a K step
 // is TWO phases of {fragment reads of both k halves | 4 MI MFMAs 16x16x128}, half the K steps per layer; bias / ReLU epilogue only.
-// PH2 (bf16): the fp8 instance's two fat phases per K step (both k halves of four column fragments per phase: 8 MI MFMAs between
-// barriers instead of 4 MI), for the 192-row tile whose registers have room for the second set of fragments.
-// NB: ONE barrier per K step instead of eight (experiment): the phase barriers only enforce the alternation of the two wave groups,
-// correctness needs a barrier between "step s+1's tile has landed for every wave" and its first read, and between the last read of a
-// ring slot and its restaging - both are met by one barrier at the top of a step.  All eight waves then run the same program and
-// the hardware interleaves the two waves of a SIMD as it sees fit.
-// PF (bf16, full width, staggered, no column blocks / K slices): the fragment reads of phase p + 1 are issued INSIDE phase p's MFMA
-// block (between its column groups, into a second set of fragment registers) instead of in the slot before phase p + 1's barrier.
-// What the ablations of round 3 say (profiles/r3_halo8_prefetch.txt): MFMAs + barriers alone run a head-tower layer in 0.118 ms, the
-// fragment reads add 0.016 and the staging issues 0.021 - both because they make the READING group's slot longer than the
-// multiplying group's 16 MFMAs.  With the reads in the shadow of the wave's own MFMAs the reading slot holds only the LDS-DMA issues.
-// Consequences: a stage must have landed one slot earlier (the counted wait moves from phase 4 to phase 3, and a step issues all four
-// pieces of the B tile of step s + 2, so that B(s + 1) is entirely older than anything of step s), and the first phase of a tile reads
-// its fragments after compute_tile (the only exposed LDS latency, once per tile).
-template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2, bool PH2 = false, bool NB = false, bool PF = false>
+// (Round 2-3 experiments on this loop, all measured slower or level and removed from the library in round 4 - the texts are in profiles/:
+// two fat phases per bf16 K step, ONE barrier per K step (r2_v3_halo8_ablation.txt), the next phase's fragment reads inside the MFMA
+// block (r3_halo8_prefetch.txt), the filters straight into registers (r3_gen7_filters_in_registers.txt).)
+template <int KW, int MI, bool STAGGER, int EPI, bool SPLIT, int NW = 8, int ES = 2>
 __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Params p) {
-    static_assert(!PF || (STAGGER && !SPLIT && NW == 8 && ES == 2 && !PH2 && !NB), "the prefetching step: full width bf16, staggered, whole tiles");
-    static_assert(!NB || (!STAGGER && ES == 2 && NW == 8 && !PH2), "the one-barrier step: full width bf16, no stagger");
-    static_assert(!PH2 || (ES == 2 && NW == 8 && MI <= 3), "two-phase bf16 steps: full width, 192-row tiles");
     static_assert(NW == 8 || (NW == 4 && !SPLIT), "the half-width instance: no column blocks / K slices");
     static_assert(ES == 2 || (ES == 1 && NW == 8 && EPI == 0 && !SPLIT), "the fp8 instance: full width, plain epilogue");
     constexpr int NBP = NW / 2;                        // 64-row pieces of a B stage
@@ -352,10 +338,9 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #pragma unroll
         for (int d = 0; d < NBP; ++d) stage_b(d, kc0, 0);
 #pragma unroll
-        for (int d = 0; d < NBP - (PF ? 0 : 1); ++d) stage_b(d, kc0 + (unsigned)(nchunk * 128), 1);
+        for (int d = 0; d < NBP - 1; ++d) stage_b(d, kc0 + (unsigned)(nchunk * 128), 1);
     }
-    if (PF)           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (NW == 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (NW == 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
@@ -431,38 +416,6 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }                                                                                            \
         H8_MFMA(1)                                                                                   \
     }
-#define H8_STEP_NB(KWI)                                                                              \
-    {                                                                                                \
-        const unsigned kc_n1 = (KWI) + 1 < KW ? kcol_g + ((KWI) + 1) * kw_stride : kcol_g1;          \
-        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
-        __builtin_amdgcn_s_barrier();                                                                \
-        stage_b(3, kc_n1, ((KWI) + 1) % 3);                                                          \
-        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
-        stage_b(1, kc_n2, ((KWI) + 2) % 3);                                                          \
-        stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
-        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);             \
-        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);     \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                        \
-            uint4 fa[MI];                                                                            \
-            _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                        \
-                fa[i_] = *reinterpret_cast<const uint4*>(lds + (arow[KWI][i_] ^ (ks_ * 64u)));       \
-            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                       \
-                uint4 fb[4];                                                                         \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
-                    fb[j_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ (ks_ * 64u)) + (KWI) * B_STAGE + (h_ * 4 + j_) * 2048); \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                     \
-                    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                \
-                        acc[i_][h_ * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
-                            __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][h_ * 4 + j_], 0, 0, 0); \
-            }                                                                                        \
-        }                                                                                            \
-        {                                                                                            \
-            constexpr int na_ = (KWI) < 2 ? ((2 * (KWI) < MI) + (2 * (KWI) + 1 < MI)) : 0;           \
-            if (na_ == 2)      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                      \
-            else if (na_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                      \
-            else               asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                      \
-        }                                                                                            \
-    }
     // The fp8 step: phase A = column fragments 0-3 (A fragments of BOTH k halves are read here and kept), phase B = fragments 4-7.
     // DMA slots: the last piece of step s+1's B tile in phase A, the first three of step s+2's in phase B (their ring slot was last
     // read in phase B of the step before, by the lagging wave group during this step's phase A).
@@ -472,13 +425,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
     __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                            \
-            if constexpr (ES == 1) mma_fp8(acc[i_][(HALF) * 4 + j_], fa[i_], fa1[i_], fb[j_], fb1[j_]); \
-            else {                                                                                   \
-                acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-                    __builtin_bit_cast(bf16x8, fa[i_]), __builtin_bit_cast(bf16x8, fb[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
-                acc[i_][(HALF) * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-                    __builtin_bit_cast(bf16x8, fa1[i_]), __builtin_bit_cast(bf16x8, fb1[j_]), acc[i_][(HALF) * 4 + j_], 0, 0, 0); \
-            }                                                                                        \
+            mma_fp8(acc[i_][(HALF) * 4 + j_], fa[i_], fa1[i_], fb[j_], fb1[j_]);                      \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_barrier();
@@ -511,9 +458,6 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }                                                                                            \
         H8_MFMA8(1)                                                                                  \
     }
-    // (PH2 with the LDS-DMA issues moved behind each phase's MFMAs - "in the shadow" of the matrix work - and the whole B tile of step
-    // s+2 issued during step s was measured 15 % SLOWER, 0.174 vs 0.152 ms: the issuing wave reaches its barrier later, and it is the
-    // multiplying group the other one waits for.  The staging issues belong to the reading group's phase.)
     // The half-width step: phase A = k half 0 + the LAST piece of step s+1's B tile, phase B = k half 1 + the FIRST piece of step
     // s+2's (its ring slot was last read two phases ago), halo pieces of the next group in both phases of taps 0 and 1.
 #define H8_STEP4(KWI)                                                                                \
@@ -536,87 +480,12 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         }                                                                                            \
         H8_MFMA(0)                                                                                   \
     }
-    // The prefetching step (PF).  Fragment sets: pfa[0] / pfa[1] = the A fragments of k half 0 / 1, pfb[0] / pfb[1] = the B fragments of
-    // the odd / even phases.  Phase p multiplies from the sets filled during phase p - 1 and fills the other ones between its
-    // column groups (a sched_barrier after each group keeps the reads there).  DMA slots: piece d of the B tile of step s + 2 in
-    // phase d + 1, halo pieces of the next group in phases 2 and 4 of taps 0 and 1; the counted wait of phase 3 covers everything
-    // issued before this step (B(s + 1), and by tap 2 the next group's halo).  MORE: false in the last step of a tile (the next tile's
-    // fragment offsets do not exist yet: its first phase reads late).
-#define H8_PF_MMA(ASET, BSET, HALF, J_)                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                                \
-        acc[i_][(HALF) * 4 + (J_)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                        \
-            __builtin_bit_cast(bf16x8, pfa[ASET][i_]), __builtin_bit_cast(bf16x8, pfb[BSET][J_]), acc[i_][(HALF) * 4 + (J_)], 0, 0, 0);
-#define H8_PF_RB(BSET, J_, SLOT, KS, HALF)                                                           \
-    pfb[BSET][J_] = *reinterpret_cast<const uint4*>(lds + (b_lane ^ ((KS) * 64u)) + (SLOT) * B_STAGE + ((HALF) * 4 + (J_)) * 2048);
-#define H8_PF_RA(ASET, I_, KWI, KS, TOG)                                                             \
-    if ((I_) < MI) pfa[ASET][(I_) < MI ? (I_) : 0] = *reinterpret_cast<const uint4*>(lds + ((arow[KWI][(I_) < MI ? (I_) : 0] ^ (TOG)) ^ ((KS) * 64u)));
-#define H8_PF_OPEN                                                                                   \
-    __builtin_amdgcn_s_barrier();                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    __builtin_amdgcn_s_setprio(1);
-#define H8_PF_CLOSE                                                                                  \
-    __builtin_amdgcn_s_setprio(0);                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    __builtin_amdgcn_s_barrier();
-#define H8_PF_FENCE __builtin_amdgcn_sched_barrier(0);
-#define H8_STEP_PF(KWI, MORE)                                                                        \
-    {                                                                                                \
-        const unsigned kc_n2 = (KWI) + 2 < KW ? kcol_g + ((KWI) + 2) * kw_stride : kcol_g1 + ((KWI) + 2 - KW) * kw_stride; \
-        constexpr int nxt_ = ((KWI) + 1) % 3;                  /* ring slot of step s + 1 = tap of its fragment offsets */ \
-        const unsigned tog_ = (KWI) == 2 ? A_TOGGLE : 0u;      /* ... which, after tap 2, lie in the other halo buffer */ \
-        /* phase 1: k half 0, columns 0-3 */                                                         \
-        stage_b(0, kc_n2, ((KWI) + 2) % 3);                                                          \
-        H8_PF_OPEN                                                                                   \
-        H8_PF_MMA(0, 0, 0, 0) H8_PF_FENCE H8_PF_RB(1, 0, KWI, 0, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(0, 0, 0, 1) H8_PF_FENCE H8_PF_RB(1, 1, KWI, 0, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(0, 0, 0, 2) H8_PF_FENCE H8_PF_RB(1, 2, KWI, 0, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(0, 0, 0, 3) H8_PF_FENCE H8_PF_RB(1, 3, KWI, 0, 1)                                  \
-        H8_PF_CLOSE                                                                                  \
-        /* phase 2: k half 0, columns 4-7 */                                                         \
-        stage_b(1, kc_n2, ((KWI) + 2) % 3);                                                          \
-        if (2 * (KWI) < MI && (KWI) < 2) stage_a(2 * (KWI), kh1, cc1, a_cur ^ A_TOGGLE);             \
-        H8_PF_OPEN                                                                                   \
-        H8_PF_MMA(0, 1, 1, 0) H8_PF_FENCE H8_PF_RB(0, 0, KWI, 1, 0) H8_PF_RA(1, 0, KWI, 1, 0u) H8_PF_FENCE \
-        H8_PF_MMA(0, 1, 1, 1) H8_PF_FENCE H8_PF_RB(0, 1, KWI, 1, 0) H8_PF_RA(1, 1, KWI, 1, 0u) H8_PF_FENCE \
-        H8_PF_MMA(0, 1, 1, 2) H8_PF_FENCE H8_PF_RB(0, 2, KWI, 1, 0) H8_PF_RA(1, 2, KWI, 1, 0u) H8_PF_FENCE \
-        H8_PF_MMA(0, 1, 1, 3) H8_PF_FENCE H8_PF_RB(0, 3, KWI, 1, 0) H8_PF_RA(1, 3, KWI, 1, 0u)       \
-        H8_PF_CLOSE                                                                                  \
-        /* phase 3: k half 1, columns 0-3; everything issued before this step has landed */          \
-        stage_b(2, kc_n2, ((KWI) + 2) % 3);                                                          \
-        {                                                                                            \
-            constexpr int na_ = (2 * (KWI) < MI && (KWI) < 2) ? 1 : 0;                               \
-            if (na_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                           \
-            else          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                           \
-        }                                                                                            \
-        H8_PF_OPEN                                                                                   \
-        H8_PF_MMA(1, 0, 0, 0) H8_PF_FENCE H8_PF_RB(1, 0, KWI, 1, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(1, 0, 0, 1) H8_PF_FENCE H8_PF_RB(1, 1, KWI, 1, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(1, 0, 0, 2) H8_PF_FENCE H8_PF_RB(1, 2, KWI, 1, 1) H8_PF_FENCE                      \
-        H8_PF_MMA(1, 0, 0, 3) H8_PF_FENCE H8_PF_RB(1, 3, KWI, 1, 1)                                  \
-        H8_PF_CLOSE                                                                                  \
-        /* phase 4: k half 1, columns 4-7; fragments of the next step's first phase */               \
-        stage_b(3, kc_n2, ((KWI) + 2) % 3);                                                          \
-        if (2 * (KWI) + 1 < MI && (KWI) < 2) stage_a(2 * (KWI) + 1, kh1, cc1, a_cur ^ A_TOGGLE);     \
-        H8_PF_OPEN                                                                                   \
-        H8_PF_MMA(1, 1, 1, 0) H8_PF_FENCE if (MORE) { H8_PF_RB(0, 0, nxt_, 0, 0) H8_PF_RA(0, 0, nxt_, 0, tog_) } H8_PF_FENCE \
-        H8_PF_MMA(1, 1, 1, 1) H8_PF_FENCE if (MORE) { H8_PF_RB(0, 1, nxt_, 0, 0) H8_PF_RA(0, 1, nxt_, 0, tog_) } H8_PF_FENCE \
-        H8_PF_MMA(1, 1, 1, 2) H8_PF_FENCE if (MORE) { H8_PF_RB(0, 2, nxt_, 0, 0) H8_PF_RA(0, 2, nxt_, 0, tog_) } H8_PF_FENCE \
-        H8_PF_MMA(1, 1, 1, 3) H8_PF_FENCE if (MORE) { H8_PF_RB(0, 3, nxt_, 0, 0) H8_PF_RA(0, 3, nxt_, 0, tog_) } \
-        H8_PF_CLOSE                                                                                  \
-    }
     static_assert(KW == 3 && MI >= 2 && MI <= 4, "the B ring (3 stages) and the halo piece slots are laid out for KW = 3, MI <= 4");
 
     const unsigned kw_stride = (unsigned)(nchunk * 128);           // K bytes between the taps of a kernel row
-    uint4 pfa[2][PF ? MI : 1], pfb[2][PF ? 4 : 1];
     while (rt < p.ntiles) {
         int gi, m0;
         compute_tile(rt, gi, m0);
-        if constexpr (PF) {                            // the first phase of a tile reads late (its stages landed behind the last wait + barrier)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) pfa[0][i] = *reinterpret_cast<const uint4*>(lds + arow[0][i]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pfb[0][j] = *reinterpret_cast<const uint4*>(lds + b_lane + j * 2048);
-        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -640,16 +509,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
 #endif
             const unsigned kcol_g = cboff + (unsigned)((kh * KW * nchunk + cc) * 128);
             const unsigned kcol_g1 = cboff1 + (unsigned)((kh1 * KW * nchunk + cc1) * 128);
-            if constexpr (PF) {
-                const bool more_ = g + 1 < gps;
-                H8_STEP_PF(0, true)
-                H8_STEP_PF(1, true)
-                H8_STEP_PF(2, more_)
-            } else if constexpr (NB) {
-                H8_STEP_NB(0)
-                H8_STEP_NB(1)
-                H8_STEP_NB(2)
-            } else if constexpr (ES == 1 || PH2) {
+            if constexpr (ES == 1) {
                 H8_STEP8F(0)
                 H8_STEP8F(1)
                 H8_STEP8F(2)
@@ -867,15 +727,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
         // item past the end are zeros from out-of-range offsets
     }
 #undef H8_STEP4
-#undef H8_STEP_PF
-#undef H8_PF_FENCE
-#undef H8_PF_CLOSE
-#undef H8_PF_OPEN
-#undef H8_PF_RA
-#undef H8_PF_RB
-#undef H8_PF_MMA
 #undef H8_STEP8F
-#undef H8_STEP_NB
 #undef H8_MFMA8
 #undef H8_STEP
 #undef H8_MFMA
@@ -947,12 +799,6 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     }
     if (S > 1 && !query && (!ws || ((uintptr_t)ws & 15))) return 1;
     const bool split = ncb > 1 || S > 1;
-    const bool nb = !q8 && !half && !split && epi == 0 && rtn_env_int("RTN_CONV_H8_NB", 0) != 0;
-    // the prefetching step (PF): RTN_CONV_H8_PF = 1 on the 192-row tile only (the 256-row instance has no registers for the second
-    // fragment set), 2 on both, 0 off
-    const int pf_env = rtn_env_int("RTN_CONV_H8_PF", 0);
-    const bool pf = !q8 && !half && !split && stagger && !nb && (pf_env == 2 || (pf_env == 1 && mi == 3));
-    const bool ph2 = !q8 && !half && !split && epi == 0 && mi == 3 && stagger && rtn_env_int("RTN_CONV_H8_PH2", 0) != 0;
     const int TM = 64 * mi - 3;
     long long tiles = 0;
     for (int i = 0; i < d->ngroups; ++i) {
@@ -1061,47 +907,9 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 8, 1>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
-#define RTN_H8_LAUNCH_PH2()                                                                              \
-    do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, 3, true, 0, false, 8, 2, true>, \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
-        }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, 3, true, 0, false, 8, 2, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
-    } while (0)
-#define RTN_H8_LAUNCH_PFE(M_, EP)                                                                        \
-    do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, EP, false, 8, 2, false, false, true>, \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
-        }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, EP, false, 8, 2, false, false, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
-    } while (0)
-#define RTN_H8_LAUNCH_PF(M_)                                                                             \
-    do {                                                                                                 \
-        if (epi == 0) RTN_H8_LAUNCH_PFE(M_, 0); else if (epi == 1) RTN_H8_LAUNCH_PFE(M_, 1);             \
-        else if (epi == 2) RTN_H8_LAUNCH_PFE(M_, 2); else RTN_H8_LAUNCH_PFE(M_, 3);                      \
-    } while (0)
-#define RTN_H8_LAUNCH_NB(M_)                                                                             \
-    do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, false, 0, false, 8, 2, false, true>, \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
-        }                                                                                                \
-        hipLaunchKernelGGL((conv_halo8_kernel<3, M_, false, 0, false, 8, 2, false, true>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
-    } while (0)
 #define RTN_H8_PICK(M_)                                                                                  \
     do {                                                                                                 \
         if (q8) RTN_H8_LAUNCH8F(3);                                                                      \
-        else if (pf) RTN_H8_LAUNCH_PF(M_);                                                               \
-        else if (nb) RTN_H8_LAUNCH_NB(M_);                                                               \
-        else if (ph2) RTN_H8_LAUNCH_PH2();                                                               \
         else if (half) RTN_H8_LAUNCH4(M_);                                                               \
         else if (split) RTN_H8_LAUNCH(M_, true, 0, true);                                                \
         else if (!stagger && epi == 0) RTN_H8_LAUNCH(M_, false, 0, false);      /* lockstep variant: A/B only */ \
@@ -1112,10 +920,6 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
     if (mi == 4) RTN_H8_PICK(4); else RTN_H8_PICK(3);
 #undef RTN_H8_PICK
-#undef RTN_H8_LAUNCH_NB
-#undef RTN_H8_LAUNCH_PF
-#undef RTN_H8_LAUNCH_PFE
-#undef RTN_H8_LAUNCH_PH2
 #undef RTN_H8_LAUNCH8F
 #undef RTN_H8_LAUNCH4
 #undef RTN_H8_LAUNCH4E

@@ -13,7 +13,7 @@ struct rtn_ctx {
     int num_cus;
     int last_conv_impl;
          // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
-    int last_wgrad_impl;          // rtn_debug_last_wgrad_impl: 1 = rtn_wgrad_halo.hip, 2 = 256x256 LDS-DMA, 3 = 128x128 LDS-DMA, 4 = rtn_wgrad_win.hip, 0 = register-staged
+    int last_wgrad_impl;          // rtn_debug_last_wgrad_impl: 2 = 256x256 LDS-DMA, 3 = 128x128 LDS-DMA, 4 = rtn_wgrad_win.hip, 0 = register-staged
     char err[512];
 };
 
@@ -50,16 +50,12 @@ int rtn_env_int(const char* name, int dflt);
 void rtn_env_sync();
 int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool stagger, bool forced, int mi_force, float* ws,
                        long long ws_cap, size_t* query, int ksplit_force, const rtn_conv_fp8_t* q8 = nullptr);
-// rtn_conv_halo8r.hip: generation 4's tile with the filters loaded from a fragment-order copy (d->w_frag) straight into registers
-int rtn_conv_halo8r_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool forced, int mi_force);
-size_t rtn_wgrad_halo_workspace_bytes(const rtn_conv_desc_t* d);
 struct rtn_wgrad_frag_t { int ncb, C, Ktot, wpt, co_tile; };   // slabs in the accumulator-fragment order of rtn_wgrad_win.hip (ncb > 0): waves per tile in the slab (8 / 4), filters per tile (128 / 64)
 int rtn_wgrad_finish(rtn_handle_t h, float* dW, const float* slab, int S, long long NK, float* db, const float* bslab, int N, int db_n,
                      int bS = 0 /* parts of bslab when not S */, const rtn_wgrad_frag_t* frag = nullptr);
 // rtn_wgrad_win.hip: all nine taps of a 128-filter x 64-channel block per workgroup over a sliding window of the input
 size_t rtn_wgrad_win_workspace_bytes(const rtn_conv_desc_t* d);
 int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);
-int rtn_wgrad_halo_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float* db, int db_n, void* workspace, size_t workspace_bytes);
 int rtn_conv_ksplit_finish(rtn_handle_t h, const float* slab, int S, long long M, int N, int ld, const float* bias, int relu, void* out,
                            int out_ld);
 

@@ -99,7 +99,6 @@ class Engine:
         self._side = None
         self.fp8_scales = None         # set by calibrate_fp8(): the head towers then run in fp8 (inference, bf16 engine)
         self._w8, self._w8_version = {}, -1
-        self._frag, self._frag_version = {}, -1        # fragment-order filter copies (_frag_weights)
         self.fp8_backbone = False      # calibrate_fp8(..., backbone=True): the 3x3 branch2b layers with >= 128 channels too
 
     # ------------------------------------------------------------------ weights
@@ -154,30 +153,6 @@ class Engine:
                 torch.add(bc, b1, out=bd)
             self._dual_version = self.weights_version
         return self._dual
-
-    def _frag_ok(self, name):
-        wk, bk, kh, kw, cin, cout = self.w[name]
-        if os.environ.get("RTN_CONV_H8R", "0") == "0" and os.environ.get("RTN_CONV_IMPL") != "7":
-            return False                                 # generation 7 measured slower than generation 4: copies only on request
-        return self.dtype == "bf16" and kh == 3 and kw == 3 and 128 < cout <= 256 and cin % 64 == 0 and name != "conv1"
-
-    def _frag_weights(self):
-        """Fragment-order copies of the 3x3 filters with 129..256 output channels (rtn_pack_frag_weights -> rtn_conv_desc_t.w_frag):
-        the seventh kernel generation reads them straight into its MFMA operand registers (head towers, P3, P4, res4 branch2b).
-        Copies of the flat forward weights, at fixed addresses (the plans' descriptors point to them): refreshed whenever those
-        change (load_state, an optimizer step)."""
-        if self._frag_version != self.weights_version:
-            self._bind_stream()                          # the copies are written on the stream the next launches use
-            for name in self.w:
-                if not self._frag_ok(name):
-                    continue
-                wk, bk, kh, kw, cin, cout = self.w[name]
-                if name not in self._frag or self._frag[name].numel() != 256 * wk.shape[1]:
-                    self._frag[name] = torch.empty(256 * wk.shape[1], dtype=wk.dtype, device=wk.device)
-                self.h.check(L.lib.rtn_pack_frag_weights(self.h.raw, wk.data_ptr(), self._frag[name].data_ptr(), wk.shape[0], cout,
-                                                       wk.shape[1]))
-            self._frag_version = self.weights_version
-        return self._frag
 
     # ------------------------------------------------------------------ fp8 head towers (BASELINE.json configs[4])
     TOWERS = ("pyramid_regression", "pyramid_classification")
@@ -298,8 +273,6 @@ class Engine:
         d.pad_t, d.pad_l = pad
         d.out_ld = cout if out_ld is None else out_ld
         d.flags = flags
-        if stride == 1 and self._frag_ok(name):
-            d.w_frag = self._frag_weights()[name].data_ptr()
         L.attach_conv_workspace(self.h, d)                 # split-K / tail-split slabs (P6, P7, res4-sized grids): caller-owned
         meta = {"name": name, "xs": [g._x for g in groups], "ys": [g._out for g in groups], "res": [g._res for g in groups],
                 "offs": [g._off for g in groups], "stride": stride, "pad": pad, "flags": flags,
@@ -693,8 +666,6 @@ class Engine:
         ops = plan["variants"][fused][0] if fused else plan["ops"]
         if fused and fused[1]:
             self._dual_weights()                         # refresh the concatenated filters if the weights changed
-        if self.dtype == "bf16":
-            self._frag_weights()                         # ... and the fragment-order copies of the 3x3 filters
         if not self.two_streams:
             for op in ops:
                 self._run_op(op, images)

@@ -68,7 +68,7 @@ def test_error_paths_without_gpu(pkg):
 
 def test_wgrad_workspace_sizes_without_gpu(pkg, monkeypatch):
     """rtn_conv2d_wgrad_workspace_bytes is a host function: the row-info table (16 B per 64-padded pixel) plus, unless RTN_WGRAD_SLAB=0,
-    the per-split slabs of the ordered (atomic-free) reduction; the 3x3 halo kernel's slabs where it is taken (RTN_WGRAD_HALO)."""
+    the per-split slabs of the ordered (atomic-free) reduction, or the nine-tap window kernel's slabs where that kernel is taken - always BEHIND the table."""
     L = pkg._lib
 
     def desc(H, W, cin, cout, k, B=8):
@@ -88,26 +88,22 @@ def test_wgrad_workspace_sizes_without_gpu(pkg, monkeypatch):
     d = desc(50, 84, 256, 64, 1)
     table = ((8 * 50 * 84 + 63) // 64) * 64 * 16
     monkeypatch.setenv("RTN_WGRAD_SLAB", "0")
-    monkeypatch.setenv("RTN_WGRAD_HALO", "0")
     assert table <= L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d)) < table + 256
     monkeypatch.setenv("RTN_WGRAD_SLAB", "1")
     with_slabs = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
     assert with_slabs >= table + 8 * 64 * (256 + 1) * 4             # at least 8 pixel splits of [N][K] + [N] floats
     assert (with_slabs - table) % (64 * 257 * 4) < 256               # a whole number of split slabs behind the (aligned) table
-    d3 = desc(50, 84, 256, 256, 3)                                   # res4 branch2b: the halo kernel's slabs
-    monkeypatch.setenv("RTN_WGRAD_HALO", "1")
-    halo = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3))
-    assert halo >= 16 * 256 * (9 * 256 + 1) * 4                     # 16 splits x ([N][9 C] + [N]) floats
+    d3 = desc(50, 84, 256, 256, 3)                                   # res4 branch2b
     assert L.lib.rtn_conv2d_wgrad_workspace_bytes(None) == 0
     # the nine-tap window kernel (csrc/rtn_wgrad_win.hip): S slabs of [N][9 C] accumulator fragments + S x (C / 64) bias parts of [N],
     # S = 8 x 32 / output tiles; taken by work (RTN_WGRAD_WIN unset), wherever the shape allows (1), never (0)
-    monkeypatch.setenv("RTN_WGRAD_HALO", "0")
     monkeypatch.setenv("RTN_WGRAD_WIN", "0")
     general = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3))
+    table3 = (((8 * 50 * 84 + 63) // 64) * 64 * 16 + 255) // 256 * 256
     monkeypatch.setenv("RTN_WGRAD_WIN", "1")
-    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == 32 * 256 * (9 * 256 + 4) * 4 > general      # 8 output tiles, 32 splits
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == table3 + 32 * 256 * (9 * 256 + 4) * 4 > general      # 8 output tiles, 32 splits
     monkeypatch.delenv("RTN_WGRAD_WIN")
-    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == 32 * 256 * (9 * 256 + 4) * 4                # res4 branch2b is taken by default
+    assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d3)) == table3 + 32 * 256 * (9 * 256 + 4) * 4       # res4 branch2b is taken by default
     d2 = desc(200, 334, 64, 64, 3)                                   # res2 branch2b: the 64-filter form, one output tile, 256 splits
     assert L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d2)) >= 256 * 64 * (9 * 64 + 1) * 4
     small = desc(25, 42, 256, 256, 3)                                # P5: too little work for a chip-wide grid, stays on the general kernel

@@ -242,70 +242,6 @@ def test_dgrad_on_the_persistent_kernels(pkg, handle, monkeypatch, impl, levels,
         assert err <= tol(dtype) * max(1.0, float(want.abs().max())), "dgrad err %.3e" % err
 
 
-@pytest.mark.parametrize("levels,cin,cout,B", [
-    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 4),     # head tower: five levels, 12 output tiles, stages cross levels
-    ([(25, 42)], 256, 256, 2),                # P5 / res4 branch2b-like
-    ([(40, 67)], 128, 128, 3),                # res3 branch2b: 3 output tiles, many pixel splits
-    ([(13, 21)], 512, 512, 3),                # res5 branch2b: 48 output tiles, more than one XCD's CUs
-    ([(7, 300)], 128, 256, 1),                # image rows much longer than a 62-pixel stage
-])
-def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
-    """csrc/rtn_wgrad_halo.hip: weight (+ bias) gradient of the stride-1 3x3 layers with one staged pixel image per kernel row, pixel
-    splits summed in order from slabs.  Against float64 autograd on the bf16-rounded operands, against the general kernel
-    (RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (no atomics)."""
-    L = pkg._lib
-    dtype = "bf16"
-    tdt, code = DT[dtype]
-    g = torch.Generator().manual_seed(500 + cin + cout)
-    w = q(torch.randn(3, 3, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(9 * cin), dtype).requires_grad_(True)
-    d = L.ConvDesc()
-    d.ngroups, d.batch, d.dtype = len(levels), B, code
-    d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
-    d.Crun = d.pix_stride = cin
-    d.sy = d.sx = 1
-    d.pad_t = d.pad_l = 1
-    d.out_ld = cout
-    keep, want, wantb = [], 0, 0
-    for gi, (H, W) in enumerate(levels):
-        x = q(torch.randn(B, H, W, cin, generator=g, dtype=torch.float64), dtype)
-        dy = q(torch.randn(B, H, W, cout, generator=g, dtype=torch.float64), dtype)
-        y = fwd_ref(x, w, 1, 1, 1, H, W)
-        want = want + torch.autograd.grad(y, w, dy)[0]
-        wantb = wantb + dy.sum(dim=(0, 1, 2))
-        xd, dyd = x.to(tdt).to(DEV).contiguous(), dy.to(tdt).to(DEV).contiguous()
-        keep += [xd, dyd]
-        grp = L.ConvGroup()
-        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
-        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
-        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
-        grp.out, grp.out_elems, grp.out_img_stride = dyd.data_ptr(), dyd.numel(), H * W * cout
-        d.g[gi] = grp
-    wantm = want.permute(3, 0, 1, 2).reshape(cout, -1)
-
-    def run(halo):
-        monkeypatch.setenv("RTN_WGRAD_HALO", "1" if halo else "0")
-        monkeypatch.setenv("RTN_WGRAD_WIN", "0")
-        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-        dW = torch.full((cout, 9 * cin), 0.5, dtype=torch.float32, device=DEV)
-        db = torch.full((cout,), 0.25, dtype=torch.float32, device=DEV)
-        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
-        torch.cuda.synchronize()
-        assert (L.lib.rtn_debug_last_wgrad_impl(handle.raw) == 1) == halo      # 0 / 2 / 3: the general kernels
-        return dW.cpu(), db.cpu()
-
-    dW1, db1 = run(True)
-    scale = max(1.0, float(wantm.abs().max()))
-    err = float((dW1.double() - 0.5 - wantm).abs().max())
-    assert err <= tol(dtype) * scale, "wgrad err %.3e scale %.2f" % (err, scale)
-    errb = float((db1.double() - 0.25 - wantb).abs().max())
-    assert errb <= tol(dtype) * max(1.0, float(wantb.abs().max())), "bias grad err %.3e" % errb
-    dW2, db2 = run(True)
-    assert torch.equal(dW1, dW2) and torch.equal(db1, db2)                 # ordered sums: the same bits every time
-    dW0, db0 = run(False)                                                   # the general kernel (float atomics): same values, other order
-    assert float((dW0 - dW1).abs().max()) <= 1e-3 * scale
-    assert float((db0 - db1).abs().max()) <= 1e-3 * max(1.0, float(wantb.abs().max()))
-
 
 @pytest.mark.parametrize("levels,cin,cout,B,bias", [
     ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, 4, True),     # head tower: five levels, runs change level inside a split
@@ -324,7 +260,7 @@ def test_wgrad_halo_kernel(pkg, handle, monkeypatch, levels, cin, cout, B):
 def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bias):
     """csrc/rtn_wgrad_win.hip: weight (+ bias) gradient of the stride-1 3x3 layers with all nine taps in one output tile over a
     sliding window of the input.  Against float64 autograd on the bf16-rounded operands, against the general kernels
-    (RTN_WGRAD_WIN=0, RTN_WGRAD_HALO=0), and bit-for-bit against itself on a second launch (ordered slab sums).
+    (RTN_WGRAD_WIN=0), and bit-for-bit against itself on a second launch (ordered slab sums).
     bias == "concat": the levels' dY lie one after another inside one [B, cells of all levels, cout] tensor (the head outputs)."""
     L = pkg._lib
     dtype = "bf16"
@@ -366,7 +302,6 @@ def test_wgrad_window_kernel(pkg, handle, monkeypatch, levels, cin, cout, B, bia
 
     def run(win):
         monkeypatch.setenv("RTN_WGRAD_WIN", "1" if win else "0")
-        monkeypatch.setenv("RTN_WGRAD_HALO", "0")
         wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
         ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
         dW = torch.full((cout, 9 * cin), 0.5, dtype=torch.float32, device=DEV)
@@ -666,58 +601,6 @@ def test_pack_dgrad_multi_equals_per_layer_pack(pkg, handle):
     for wd, ref in want:
         assert torch.equal(wd, ref)
 
-
-def test_wgrad_ring_kernel_equals_the_two_stage_kernel_bit_for_bit(pkg, handle, monkeypatch):
-    """conv_wgrad_ring_kernel (256 x 256 tile, 32-pixel stages in a ring of four, row info through scalar loads, counted vmcnt) adds
-    the same bf16 products in the same order as conv_wgrad_dma_kernel<4, 2, 8> (64-pixel steps, two stages): a head-tower-like layer
-    over five levels with the bias gradient fused, pixel counts that end in the middle of a 64-pixel tile, and a split boundary
-    inside a level - dW and db must be identical bits (RTN_WGRAD_RING=0 selects the two-stage kernel)."""
-    L = pkg._lib
-    tdt, code = DT["bf16"]
-    B, cin, cout = 2, 256, 512
-    levels = [(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)]
-    g = torch.Generator().manual_seed(23)
-    total = sum(h * w for h, w in levels)
-    dy = torch.randn(B, total, cout, generator=g).to(tdt).to(DEV).contiguous()
-    d = L.ConvDesc()
-    d.ngroups, d.batch, d.dtype = len(levels), B, code
-    d.w_rows, d.N, d.KH, d.KW = cout, cout, 3, 3
-    d.Crun = d.pix_stride = cin
-    d.sy = d.sx = 1
-    d.pad_t = d.pad_l = 1
-    d.out_ld = cout
-    keep, off = [], 0
-    for gi, (H, W) in enumerate(levels):
-        xd = torch.randn(B, H, W, cin, generator=g).to(tdt).to(DEV).contiguous()
-        keep.append(xd)
-        grp = L.ConvGroup()
-        grp.in_, grp.in_elems = xd.data_ptr(), xd.numel()
-        grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
-        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
-        grp.out, grp.out_elems = dy.data_ptr(), dy.numel()
-        grp.out_img_stride, grp.out_off = total * cout, off * cout
-        d.g[gi] = grp
-        off += H * W
-    monkeypatch.setenv("RTN_WGRAD_DMA", "2")
-    monkeypatch.setenv("RTN_WGRAD_WIN", "0")
-    got = {}
-    for ring in ("0", "1", "1"):
-        monkeypatch.setenv("RTN_WGRAD_RING", ring)
-        wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
-        dW = torch.zeros(cout, 9 * cin, dtype=torch.float32, device=DEV)
-        db = torch.zeros(cout, dtype=torch.float32, device=DEV)
-        handle.check(L.lib.rtn_conv2d_wgrad_bias(handle.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
-        torch.cuda.synchronize()
-        assert L.lib.rtn_debug_last_wgrad_impl(handle.raw) == 2
-        got.setdefault(ring, []).append((dW.cpu(), db.cpu()))
-    (w0, b0), (w1, b1), (w2, b2) = got["0"][0], got["1"][0], got["1"][1]
-    assert float(w0.abs().max()) > 1.0
-    assert torch.equal(w1, w2) and torch.equal(b1, b2)
-    assert torch.equal(w0, w1), "ring kernel differs from the two-stage kernel: max %.3e" % float((w0 - w1).abs().max())
-    assert torch.equal(b0, b1)
-    want_db = dy.float().cpu().double().sum(dim=(0, 1))
-    assert float((b1.double() - want_db).abs().max()) <= 1e-4 * float(want_db.abs().max())
 
 
 @pytest.mark.parametrize("H,W,cin,cout,B,grid,mode", [

@@ -49,7 +49,7 @@ def pack_w(w_hwio, dtype, dev):
 
 
 def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res_mode=None, B=2, seed=0, out_ld=None,
-             concat=False, reference=True, frag=False):
+             concat=False, reference=True):
     """levels: list of (H, W). Returns (got list, want list) per level (f64, NHWC)."""
     L = pkg._lib
     dev = torch.device("cuda")
@@ -67,10 +67,6 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
     d.w, d.bias, d.w_rows, d.N, d.KH, d.KW = wk.data_ptr(), bk.data_ptr(), rows, cout, k, k
     d.Crun = d.pix_stride = cin
     d.sy = d.sx = stride
-    if frag:                                      # the filters once more, in MFMA-fragment order (generation 7 reads them into registers)
-        wf = torch.empty(256 * k * k * cin, dtype=tdt, device=dev)
-        handle.check(L.lib.rtn_pack_frag_weights(handle.raw, wk.data_ptr(), wf.data_ptr(), rows, cout, k * k * cin))
-        d.w_frag = wf.data_ptr()
     out_f32 = bool(flags & L.CONV_OUT_F32) or dtype == "f32"
     odt = torch.float32 if out_f32 else tdt
     ld = cout if out_ld is None else out_ld
@@ -372,106 +368,6 @@ def test_gemm8_narrow_instance_for_128_columns(pkg, handle, monkeypatch, levels,
     for a, b in zip(out["1"][0], out["0"][0]):
         assert torch.equal(a, b), "narrow and wide instances differ by %.3e" % float((a - b).abs().max())
 
-
-@pytest.mark.parametrize("mi", [4, 3])
-@pytest.mark.parametrize("levels,cin,cout,relu,res,B,grid", [
-    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, True, None, 2, 0),   # head-tower shape: five levels, one grouped launch
-    ([(40, 67)], 256, 256, False, None, 3, 3),      # P3-like; 32 tiles on 3 workgroups: every workgroup walks ~11 tiles
-    ([(25, 42), (13, 21)], 128, 200, True, None, 2, 1),   # two chunks per tap, N < 256 (zero filters behind N), ONE workgroup walks all tiles
-    ([(7, 300)], 256, 136, True, None, 1, 2),       # rows longer than a tile: tiles start and end inside an image row
-    ([(3, 5)], 256, 256, True, None, 1, 0),         # a single, mostly empty tile
-    ([(1, 40)], 64, 256, True, None, 2, 0),         # one-row images, one chunk per tap
-    ([(30, 1)], 128, 256, False, None, 2, 2),       # one-column images: both side taps leave the image everywhere
-    ([(40, 67)], 256, 256, False, "same", 2, 3),    # residual epilogue (accumulated data gradients)
-])
-def test_generation7_filters_in_registers(pkg, handle, monkeypatch, levels, cin, cout, relu, res, B, grid, mi):
-    """Generation 7 (csrc/rtn_conv_halo8r.hip): generation 4's tiles with the filters read from a fragment-order copy
-    (rtn_pack_frag_weights -> rtn_conv_desc_t.w_frag) straight into the MFMA operand registers.  Against the float64 convolution
-    of the bf16-rounded operands, and BIT FOR BIT against generation 4 (same products, same summation order per output element)."""
-    L = pkg._lib
-    monkeypatch.setenv("RTN_CONV_IMPL", "7")
-    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
-    monkeypatch.setenv("RTN_CONV_H8_MI", str(mi))
-    flags = (L.CONV_RELU if relu else 0) | (L.CONV_RES_SAME if res else 0)
-    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=70 + grid, frag=True)
-    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 7
-    check(gots, wants, ld, n, "bf16")
-    monkeypatch.setenv("RTN_CONV_IMPL", "4")
-    monkeypatch.setenv("RTN_CONV_H8_KSPLIT", "1")            # generation 4 without K slices (their f32 partial sums change the order)
-    gots4, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=70 + grid, reference=False)
-    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
-    for a, b in zip(gots, gots4):
-        assert torch.equal(a, b), "generations 7 and 4 differ by %.3e" % float((a - b).abs().max())
-
-
-def test_generation7_repeats_bit_for_bit(pkg, handle, monkeypatch):
-    """6 launches of a head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) on generation 7 give the same
-    bits at both tile heights: no halo piece lands after a fragment read, no weight fragment is multiplied before it arrived."""
-    L = pkg._lib
-    monkeypatch.setenv("RTN_CONV_IMPL", "7")
-    levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
-    first = None
-    for it in range(6):
-        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 4 else "3")
-        gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
-                                      reference=(it == 0), frag=True)
-        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 7
-        if first is None:
-            check(gots, wants, ld, n, "bf16")
-            first = gots
-        else:
-            for a, b in zip(gots, first):
-                assert torch.equal(a, b), "launch %d differs" % it
-
-
-@pytest.mark.parametrize("mi", [3, 4])
-@pytest.mark.parametrize("levels,cin,cout,relu,res,B,grid", [
-    ([(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)], 256, 256, True, None, 2, 0),   # head-tower shape: five levels, one grouped launch
-    ([(40, 67)], 256, 256, False, None, 3, 3),      # 32 tiles on 3 workgroups: every workgroup walks ~11 tiles (late reads at each tile start)
-    ([(25, 42), (13, 21)], 128, 200, True, None, 2, 1),   # two chunks per tap, N not a multiple of 16, ONE workgroup walks all tiles
-    ([(7, 300)], 256, 136, True, None, 1, 2),       # rows longer than a tile
-    ([(3, 5)], 256, 256, True, None, 1, 0),         # a single, mostly empty tile
-    ([(1, 40)], 64, 256, True, None, 2, 0),         # one chunk per tap: a group is three K steps
-    ([(40, 67)], 256, 256, False, "same", 2, 3),    # residual epilogue
-])
-def test_halo8_prefetching_step(pkg, handle, monkeypatch, levels, cin, cout, relu, res, B, grid, mi):
-    """RTN_CONV_H8_PF: generation 4 with the fragment reads of phase p + 1 issued inside phase p's MFMA block (second fragment set,
-    counted wait one phase earlier, four B pieces of step s + 2 per step).  Same products, same order: BIT FOR BIT the plain step."""
-    L = pkg._lib
-    monkeypatch.setenv("RTN_CONV_IMPL", "4")
-    monkeypatch.setenv("RTN_CONV_H8_KSPLIT", "1")
-    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
-    monkeypatch.setenv("RTN_CONV_H8_MI", str(mi))
-    flags = (L.CONV_RELU if relu else 0) | (L.CONV_RES_SAME if res else 0)
-    monkeypatch.setenv("RTN_CONV_H8_PF", "2")
-    gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=40 + grid)
-    assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
-    check(gots, wants, ld, n, "bf16")
-    monkeypatch.setenv("RTN_CONV_H8_PF", "0")
-    gots0, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 3, 1, "same", flags, res, B=B, seed=40 + grid, reference=False)
-    for a, b in zip(gots, gots0):
-        assert torch.equal(a, b), "prefetching and plain steps differ by %.3e" % float((a - b).abs().max())
-
-
-def test_halo8_prefetching_step_repeats_bit_for_bit(pkg, handle, monkeypatch):
-    """6 launches of a head-tower-sized layer with the prefetching step, both tile heights: the same bits every time (a fragment read
-    ahead of its stage's landing, or a stage rewritten under a read, would show as a tile that changes)."""
-    L = pkg._lib
-    monkeypatch.setenv("RTN_CONV_IMPL", "4")
-    monkeypatch.setenv("RTN_CONV_H8_PF", "2")
-    levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
-    first = None
-    for it in range(6):
-        monkeypatch.setenv("RTN_CONV_H8_MI", "3" if it < 4 else "4")
-        gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
-                                      reference=(it == 0))
-        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4
-        if first is None:
-            check(gots, wants, ld, n, "bf16")
-            first = gots
-        else:
-            for a, b in zip(gots, first):
-                assert torch.equal(a, b), "launch %d differs" % it
 
 
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):

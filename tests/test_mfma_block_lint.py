@@ -13,7 +13,7 @@ spec = importlib.util.spec_from_file_location("lint_mfma_blocks", os.path.join(R
 lint = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(lint)
 
-STRICT = r"conv_halo8_kernel|conv_halo8r_kernel|conv_gemm8_kernel|conv_wgrad_win_kernel"
+STRICT = r"conv_halo8_kernel|conv_gemm8_kernel|conv_wgrad_win_kernel"
 
 
 def test_lint_flags_the_round3_fp8_sequence():

@@ -11,7 +11,7 @@ SHAPES = {"tower": ([(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)], 256, 25
           "res3_2c": ([(100, 167)], 128, 512, 1), "res5_2a": ([(25, 42)], 2048, 512, 1), "res5_2c": ([(25, 42)], 512, 2048, 1),
           "res2_2a": ([(200, 334)], 256, 64, 1), "res2_2c": ([(200, 334)], 64, 256, 1), "c3": ([(100, 167)], 512, 256, 1)}
 name = sys.argv[1] if len(sys.argv) > 1 else "tower"
-variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_WGRAD_HALO=1", "RTN_WGRAD_HALO=0"])]
+variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_WGRAD_WIN=1", "RTN_WGRAD_WIN=0"])]
 levels, cin, cout = SHAPES[name][:3]
 K = SHAPES[name][3] if len(SHAPES[name]) > 3 else 3
 B = int(os.environ.get("AB_BATCH", bench.BATCH))

@@ -24,7 +24,7 @@ _scan = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_scan)
 
 GAP = 10
-DEFAULT_KERNELS = r"conv_halo8_kernel|conv_halo8r_kernel|conv_gemm8_kernel|conv_halon_kernel|conv_wgrad_win_kernel"
+DEFAULT_KERNELS = r"conv_halo8_kernel|conv_gemm8_kernel|conv_halon_kernel|conv_wgrad_win_kernel"
 _nop = re.compile(r"^(\d+)")
 
 
