@@ -6,7 +6,10 @@ starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a ch
 
 Workload (BASELINE.json configs[1]): ResNet50-FPN RetinaNet INFERENCE, 800x1333, bf16, batch 8 per GPU:
 one step = stem pack -> ResNet-50 -> FPN -> both head stacks over P3..P7 -> decode + score threshold + NMS + top-k
-for a batch of 8 synthetic 3-channel distance-transform-like pages already resident in HBM.  Inference shards by
+for a batch of 8 synthetic 3-channel distance-transform-like pages already resident in HBM.  --in-flight N (default 2): the
+engine's throughput mode - consecutive steps go to N buffer sets on N HIP streams and overlap on the device (every step still
+runs whole, into its own outputs; the timed region ends when all K steps are done); --in-flight 1 is one batch at a time, whose
+ms per step the line also carries (`config.ms_per_step_one_batch_at_a_time`).  Inference shards by
 image with no data-path collective ("scaling": "weak": per-GPU batch fixed).  Weights are seeded random-init of the
 architecture (no checkpoint exists in the reference); the classification bias is set so ~1 % of the 200,700 anchors
 per image pass the 0.05 score threshold, the load a trained detector puts on the NMS stage.
@@ -276,6 +279,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the training-step measurement (the `secondary` object)")
     ap.add_argument("--secondary-steps", type=int, default=20)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches the engine keeps in flight (Engine.in_flight): consecutive steps run on that many buffer sets, one HIP "
+                         "stream each, and overlap on the device; 1 = one batch at a time with the graph's forks on side streams")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, BASELINE.json configs[1]) or train (configs[2]/[3]: batch 16/GPU training step)")
     args = ap.parse_args()
@@ -342,12 +348,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Throughput mode: `in_flight` batches at a time.  Every step is still one whole pass over one batch of 8 (stem pack -> backbone -> FPN ->
+    # heads -> decode + NMS into that step's own output buffers); consecutive steps go to alternating buffer sets on separate HIP
+    # streams and the timed region ends only when all K of them are done (join + barrier + synchronize).
+    if args.in_flight < 1:
+        ap.error("--in-flight must be >= 1")
+    eng.in_flight = args.in_flight
+    for _ in range(max(args.warmup, 0) if args.in_flight == 1 else 0):
         eng.detect(x)
+    if args.in_flight > 1:                               # the buffer sets are built outside the W warm-up steps (a plan build is not a step)
+        for _ in range(args.in_flight):
+            eng.detect(x)
+        eng.join()
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            eng.detect(x)
+        eng.join()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         boxes, scores, labels = eng.detect(x)
+    eng.join()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -358,6 +379,17 @@ def main():
     images = n_gpus * BATCH * args.steps
     value = images / elapsed
 
+    one_ms = None
+    if args.in_flight > 1:                               # beside the line: the same steps one batch at a time (latency of a batch)
+        eng.in_flight = 1
+        for _ in range(3):
+            eng.detect(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            eng.detect(x)
+        torch.cuda.synchronize()
+        one_ms = (time.perf_counter() - t1) / 10 * 1e3
     out = None
     if rank == 0:
         # ---- roofline.  `achieved` comes from the TIMED region (algorithmic conv FLOPs of a step / ms_per_step).  Beside it:
@@ -435,6 +467,7 @@ def main():
                                       "(BASELINE.json configs[1])",
                           "batch_per_gpu": BATCH, "canvas": list(CANVAS), "anchors_per_image": plan["N"],
                           "candidates_above_0.05_per_image": ncand / BATCH, "parallelism": "dp%d (images sharded, no collective)" % n_gpus,
+                          "batches_in_flight": args.in_flight, "ms_per_step_one_batch_at_a_time": one_ms,
                           "gflop_per_image_survey": GFLOP_PER_IMAGE, "gflop_per_image_counted": flops_step / BATCH / 1e9},
                "roofline": roofline}
         if not args.no_cpu_baseline and n_gpus == 1:

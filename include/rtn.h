@@ -128,16 +128,29 @@ typedef struct {
     int32_t flags;
     int32_t reserved_;
     void*   workspace;       /* caller-owned scratch for the launches that split a K loop over workgroups (f32 partial-sum
-                                slabs of the split-K and tail-split paths), >= rtn_conv2d_workspace_bytes(h, d) bytes,
-                                16-byte aligned, used only while the launch runs: launches that may overlap in time (other
-                                streams) need different buffers.  NULL / too small = no K split for this launch (slower on
-                                the few layers that want one, same results up to f32 summation order).  */
+                                slabs of the split-K, tail-split, K-slice and stream-K paths), >= rtn_conv2d_workspace_bytes(h, d)
+                                bytes, 16-byte aligned: launches that may overlap in time (other streams) need different buffers.
+                                Its first RTN_CONV_SYNC_BYTES are the SYNC BLOCK of the in-launch reductions (stream-K: one flag
+                                per workgroup): they must be zero when a launch starts - rtn_conv_workspace_init() once after
+                                allocation does that - and every launch that completes leaves them zero again; everything behind
+                                them is scratch used only while a launch runs.  NULL / too small = no K split for this launch
+                                (slower on the layers that want one, same results up to f32 summation order).  */
     int64_t workspace_bytes;
 } rtn_conv_desc_t;
+#define RTN_CONV_SYNC_BYTES 4096
 
 /* Bytes of `workspace` the launch described by `d` can use on this device (0 for most layers).  The library never allocates:
  * every forward / dgrad entry point below takes its scratch from the descriptor. */
 size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d);
+/* Zero the sync block of a freshly allocated convolution workspace.  Once per buffer; the block is zero on return (the call
+ * synchronises the handle's stream), so the buffer may then serve launches on any stream. */
+int rtn_conv_workspace_init(rtn_handle_t h, void* workspace, size_t workspace_bytes);
+/* Workgroups of the last convolution launch on this handle if it ran in STREAM-K form (csrc/rtn_conv_gemm8.hip, rtn_conv_halo8.hip:
+ * the launch's tiles x K steps shared evenly by the workgroups, partial tiles handed over and added in a fixed order inside the
+ * launch), 0 otherwise.  rtn_debug_conv_sync_timeouts: synchronises the stream and reads the sync block's error word - the number of
+ * bounded flag polls that gave up (always 0 unless a workgroup of a launch never ran). */
+int rtn_debug_last_conv_streamk(rtn_handle_t h);
+int rtn_debug_conv_sync_timeouts(rtn_handle_t h, const void* workspace, unsigned* count);
 /* Which kernel generation the last convolution launch on this handle ran (1: 128-row register-staged, 2: 256-row LDS-DMA per tap,
  * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel).  For tests and profiles: proves which native path executed. */
 int rtn_debug_last_conv_impl(rtn_handle_t h);
@@ -164,6 +177,8 @@ typedef struct {
     int32_t step;            /* 1 or the shortcut's stride                             */
 } rtn_conv_src2_t;
 int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2);
+/* rtn_conv2d_workspace_bytes for that launch (its stream-K form; the same sync-block contract). */
+size_t rtn_conv1x1_dual_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2);
 
 /* fp8 (OCP e4m3fn) convolution for BASELINE.json configs[4] ("fp8 MFMA convs", the head towers default_classification_model /
  * default_regression_model, model/defineModel.py:78-167): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, f32 accumulate.

@@ -102,6 +102,10 @@ SIGNATURES = {
     "rtn_debug_last_wgrad_impl": (_I, [_P]),
     "rtn_conv2d_fwd": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_conv1x1_dual_fwd": (_I, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
+    "rtn_conv1x1_dual_workspace_bytes": (_SZ, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
+    "rtn_conv_workspace_init": (_I, [_P, _P, _SZ]),
+    "rtn_debug_last_conv_streamk": (_I, [_P]),
+    "rtn_debug_conv_sync_timeouts": (_I, [_P, _P, C.POINTER(C.c_uint32)]),
     "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
@@ -207,15 +211,20 @@ class Handle:
             pass
 
 
-def attach_conv_workspace(handle, d):
-    """Give a conv descriptor the scratch rtn_conv2d_workspace_bytes() asks for on this device: a uint8 device tensor kept alive
-    by the descriptor (the library never allocates; the K-split paths are skipped without it).  One buffer per descriptor, so
-    launches on different streams never share scratch.  Returns the tensor or None."""
-    n = int(lib.rtn_conv2d_workspace_bytes(handle.raw, C.byref(d)))
+def attach_conv_workspace(handle, d, s2=None):
+    """Give a conv descriptor the scratch rtn_conv2d_workspace_bytes() (with `s2`: rtn_conv1x1_dual_workspace_bytes()) asks for on
+    this device: a uint8 device tensor kept alive by the descriptor (the library never allocates; the K-split paths are skipped
+    without it).  One buffer per descriptor, so launches on different streams never share scratch.  Its sync block (the first
+    RTN_CONV_SYNC_BYTES) is zeroed here, once, on the handle's stream (rtn_conv_workspace_init).  Returns the tensor or None."""
+    if s2 is None:
+        n = int(lib.rtn_conv2d_workspace_bytes(handle.raw, C.byref(d)))
+    else:
+        n = int(lib.rtn_conv1x1_dual_workspace_bytes(handle.raw, C.byref(d), C.byref(s2)))
     if n <= 0:
         d.workspace, d.workspace_bytes, d._ws = None, 0, None
         return None
     t = torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", handle.device))
+    handle.check(lib.rtn_conv_workspace_init(handle.raw, t.data_ptr(), n))
     d.workspace, d.workspace_bytes, d._ws = t.data_ptr(), n, t
     return t
 

@@ -1378,9 +1378,13 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if ((d->flags & RTN_CONV_RES_SAME) && (d->flags & RTN_CONV_RES_UPSAMPLE))
         return rtn_fail(h, RTN_EINVAL, "conv: both residual modes set");
     const bool has_res = d->flags & (RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE);
-    // caller-owned scratch of the K-split paths (never allocated here)
-    float* const ws_ptr = (!query && d->workspace && !((uintptr_t)d->workspace & 15) && d->workspace_bytes > 0) ? (float*)d->workspace : nullptr;
-    const long long ws_cap = query ? kMaxConvWorkspace : (ws_ptr ? (long long)d->workspace_bytes : 0);
+    // caller-owned scratch of the K-split paths (never allocated here).  Its first RTN_CONV_SYNC_BYTES are the sync block of the
+    // in-launch reductions (flags; zero before and after every launch, see rtn_conv_workspace_init): every slab starts behind it.
+    const bool ws_ok = !query && d->workspace && !((uintptr_t)d->workspace & 15) && d->workspace_bytes > RTN_CONV_SYNC_BYTES;
+    unsigned* const ws_sync = ws_ok ? (unsigned*)d->workspace : nullptr;
+    float* const ws_ptr = ws_ok ? (float*)((char*)d->workspace + RTN_CONV_SYNC_BYTES) : nullptr;
+    const long long ws_cap = query ? kMaxConvWorkspace : (ws_ptr ? (long long)d->workspace_bytes - RTN_CONV_SYNC_BYTES : 0);
+    if (!query) h->last_conv_streamk = 0;
 
     KParams p;
     memset(&p, 0, sizeof(p));
@@ -1473,13 +1477,15 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     }
     // Fifth generation (rtn_conv_gemm8.hip): the 1x1 layers with N % 256 == 0 and a bias / ReLU epilogue, one or two sources.
     // RTN_CONV_G8=0 turns it off, RTN_CONV_IMPL=5 forces it; RTN_CONV_G8_MI pins the tile height (2 | 3 row fragments per wave).
-    if (!query && !q8 && out8_scale == 0.f && d->dtype == RTN_BF16 && d->KH == 1 && d->KW == 1) {
+    // RTN_CONV_G8_SK: its stream-K form (-1 = cost model, 0 = never, 1 = wherever the shape allows).
+    if (!q8 && out8_scale == 0.f && d->dtype == RTN_BF16 && d->KH == 1 && d->KW == 1) {
         const int g8 = rtn_env_int("RTN_CONV_G8", 1);
         const int forced = rtn_conv_impl_override();
         if (forced == 5 || (forced == 0 && g8 != 0)) {
             const int rc = rtn_conv_gemm8_try(h, d, s2, rtn_env_int("RTN_CONV_H8_GRID", 0), rtn_env_int("RTN_CONV_H8_STAGGER", 1) != 0,
-                                              forced == 5, rtn_env_int("RTN_CONV_G8_MI", 0));
-            if (rc == RTN_OK) h->last_conv_impl = 5;
+                                              forced == 5, rtn_env_int("RTN_CONV_G8_MI", 0), ws_sync, ws_ptr, ws_cap, query,
+                                              rtn_env_int("RTN_CONV_G8_SK", -1));
+            if (rc == RTN_OK && !query) h->last_conv_impl = 5;
             if (rc <= 0) return rc;
         }
     }
@@ -1793,9 +1799,31 @@ extern "C" int rtn_conv2d_fwd(rtn_handle_t h, const rtn_conv_desc_t* d) { return
 extern "C" size_t rtn_conv2d_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d) {
     size_t n = 0;
     if (!h || !d) return 0;
-    // the K-split paths are taken by plain forward / dgrad launches only (not by the dual-source or fp8 variants)
+    // the K-split paths are taken by plain forward / dgrad launches and by the dual-source form (below), not by the fp8 variants
     if (conv_launch(h, d, nullptr, nullptr, 0.f, &n) != RTN_OK) return 0;
-    return n;
+    return n ? n + RTN_CONV_SYNC_BYTES : 0;
+}
+extern "C" size_t rtn_conv1x1_dual_workspace_bytes(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2) {
+    size_t n = 0;
+    if (!h || !d || !s2) return 0;
+    if (conv_launch(h, d, s2, nullptr, 0.f, &n) != RTN_OK) return 0;
+    return n ? n + RTN_CONV_SYNC_BYTES : 0;
+}
+extern "C" int rtn_conv_workspace_init(rtn_handle_t h, void* workspace, size_t workspace_bytes) {
+    if (!h) return RTN_EINVAL;
+    if (!workspace || ((uintptr_t)workspace & 15)) return rtn_fail(h, RTN_EINVAL, "conv workspace init: null / misaligned");
+    if (workspace_bytes < RTN_CONV_SYNC_BYTES) return rtn_fail(h, RTN_ENOMEM, "conv workspace init: %zu < %d", workspace_bytes, RTN_CONV_SYNC_BYTES);
+    RTN_HIP(h, hipMemsetAsync(workspace, 0, RTN_CONV_SYNC_BYTES, h->stream));
+    RTN_HIP(h, hipStreamSynchronize(h->stream));       // zero on return: the buffer may then serve launches on any stream
+    return RTN_OK;
+}
+extern "C" int rtn_debug_last_conv_streamk(rtn_handle_t h) { return h ? h->last_conv_streamk : RTN_EINVAL; }
+extern "C" int rtn_debug_conv_sync_timeouts(rtn_handle_t h, const void* workspace, unsigned* count) {
+    if (!h) return RTN_EINVAL;
+    if (!workspace || !count) return rtn_fail(h, RTN_EINVAL, "conv sync timeouts: null argument");
+    RTN_HIP(h, hipStreamSynchronize(h->stream));
+    RTN_HIP(h, hipMemcpy(count, (const char*)workspace + RTN_CONV_SYNC_BYTES - 4, 4, hipMemcpyDeviceToHost));
+    return RTN_OK;
 }
 
 extern "C" int rtn_conv1x1_dual_fwd(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2) {

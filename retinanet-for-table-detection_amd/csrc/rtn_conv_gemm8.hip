@@ -19,9 +19,38 @@
 //   * weight rows permuted at staging (position 16 j + c <-> channel 8 c + j): bias-initialised accumulators, ReLU, bf16 and
 //     16-byte stores straight from registers, as in generation 4; the bias vector sits in the unused tail of the first A stage.
 // LDS: A ring 3 x 32 KiB (24 KiB used, bias in the tail of stage 0), B ring 2 x 32 KiB = 160 KiB.  One workgroup per CU.
+//
+// STREAM-K (SK, round 4).  The small-M layers of stages 4 / 5 and the FPN top (M = 8,400 .. 33,600 rows) have 44 .. 175 row tiles for
+// 256 CUs and 16 .. 32 sequential K steps per tile: most of the chip idles while a third of it walks long K loops.  With SK the
+// launch's ntiles x nk K steps are ONE sequence (column block, row tile, k) cut into gridDim.x equal contiguous ranges; a workgroup
+// walks its range as the same uninterrupted stream of steps, crossing tile boundaries with the cursors it already has.  A range
+// that starts inside a tile first finishes that tile's tail: f32 partial sums in REGISTER ORDER ([slot][thread] x 16 B: every store
+// instruction writes one contiguous KiB) go to the workgroup's slab in the caller's workspace with write-through (sc1) stores, every
+// wave drains (vmcnt 0), the workgroup meets at barriers, one lane sets the workgroup's flag (relaxed agent-scope store).  A range
+// that ends inside a tile holds that tile's HEAD (k = 0 ..): it is the tile's owner - bias-initialised accumulators, polls the flags
+// of the workgroups that hold the rest of the tile (relaxed agent-scope loads by one wave, then a barrier), adds their slabs in K
+// order with sc1 loads (every load of handed-off bytes: cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Hand-offs measured
+// with sc1 loads") and runs the ordinary epilogue.  The order of the adds is fixed by (grid, ntiles, nk): same bits every run.
+// Who waits for whom: logical workgroup L = gridDim.x - 1 - blockIdx.x owns range L, the owner L of a tile waits for L + 1, L + 2, ...,
+// i.e. for LOWER block ids, which the dispatcher starts first, and only at the very END of its own range, while the tails it waits for
+// are the FIRST thing their workgroups do: no wait can depend on a wait.  The poll is bounded (2 s of the 100 MHz clock); a timeout
+// counts up the error word of the sync block and goes on (wrong values, never a hang).  Flags are reset by the owner after the poll:
+// the sync block (first 4 KiB of the workspace) is zero before and after every launch.
 #include "rtn_internal.h"
 
 namespace {
+
+// -DRTN_G8_STAMP: per-workgroup time stamps (100 MHz s_memrealtime) at the stations of the kernel, read back by rtn_debug_g8_stamps
+// (tools/g8_stamps.py).  Not in production builds.
+#ifdef RTN_G8_STAMP
+__device__ unsigned long long g_g8_stamps[1024][8];
+// slot 7: shader clocks (s_memtime) between stations 0 and 6, the whole workgroup -> its average frequency
+#define G8_STAMP(I_) if (t == 0) { g_g8_stamps[blockIdx.x][I_] = __builtin_amdgcn_s_memrealtime();                                        \
+        if ((I_) == 0 || (I_) == 6) { unsigned long long c_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_) :: "memory");  \
+            g_g8_stamps[blockIdx.x][7] = (I_) == 0 ? c_ : c_ - g_g8_stamps[blockIdx.x][7]; } }
+#else
+#define G8_STAMP(I_)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -34,6 +63,7 @@ constexpr unsigned G8_OOB = 0xFFFF0000u;              // beyond every descriptor
 constexpr int G8_THREADS = 512;
 constexpr int G8_LDS = 160 * 1024;
 constexpr unsigned G8_STAGE = 32768, G8_B_BASE = 3 * 32768, G8_BIAS_OFF = 24576;
+constexpr unsigned G8_SYNC_OFF = G8_STAGE + 24576;    // SK: two words in the unused tail of A stage 1 (tiles have at most 192 rows = 24 KiB per stage)
 
 struct G8Src {
     const char* ptr;
@@ -65,7 +95,14 @@ struct G8Params {
     int res_up, Hres, Wres;
     unsigned res_img_stride;      // elements between images of `res`
     float rs_h, rs_w;
+    // stream-K (SK instances): sk_total = ntiles * nk K steps shared evenly by the grid; slabs of one partial tile per workgroup in
+    // register order; flags[L] = 1 once workgroup L's slab is published; flags[SK_ERR_WORD] counts poll timeouts
+    int sk_total;
+    char* sk_slab;
+    unsigned sk_slab_bytes;
+    unsigned* sk_flags;
 };
+constexpr int SK_ERR_WORD = 1023;
 
 __device__ __forceinline__ i32x4 make_srd(const void* ptr, unsigned bytes) {
     const unsigned long long a = (unsigned long long)ptr;
@@ -113,8 +150,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 //   phase of step s (B first: it is L2-resident), into the slots step s-1 read last - one full phase after the lagging wave group's
 //   last read of them - and the step's one wait, vmcnt(2 + MI), retires everything older, i.e. A(s+1) and B(s+1), one phase before
 //   their first read.  A lane ends up with 4 consecutive channels of a pixel (position 16 j + c <-> channel 4 c + j): 8-byte stores.
-template <int MI, bool STAGGER, bool DUAL, int EPI, int NW = 8>
+template <int MI, bool STAGGER, bool DUAL, int EPI, int NW = 8, bool SK = false>
 __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Params p) {
+    static_assert(!SK || (NW == 8 && !(EPI & 2)), "stream-K: the 256-column tile, bias / ReLU / residual epilogues");
     constexpr int R = 64 * MI;                         // rows of a tile
     constexpr int CT = 32 * NW;                        // columns of a tile
     constexpr unsigned BSTG = NW == 8 ? G8_STAGE : G8_STAGE / 2;      // bytes of a B stage
@@ -131,6 +169,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     const int lrow = lane & 15, kq = lane >> 4;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
+    G8_STAMP(0)
     const int nk = p.nk;
     const i32x4 w_srd = make_srd(p.w, p.w_bytes);
     const i32x4 s1_srd = make_srd(p.s1.ptr, p.s1.bytes);
@@ -141,6 +180,10 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
         float* bl = reinterpret_cast<float*>(lds + G8_BIAS_OFF);
         for (int i = t; i < p.N; i += G8_THREADS) bl[i] = p.bias ? p.bias[i] : 0.f;
     }
+    // SK: [0] counts the waves that have drained their slab stores (the last one raises the global flag), [1] is set by wave 0 once the
+    // flags this workgroup waits for are up.  Each is used at most once per launch; published by the prologue's barrier.
+    unsigned* const sk_sync = reinterpret_cast<unsigned*>(lds + G8_SYNC_OFF);
+    if (SK && t == 0) { sk_sync[0] = 0u; sk_sync[1] = 0u; }
 
     // workgroup -> first tile: tiles that share an A row block (same m tile) are neighbours; workgroups b and b + 8 share an XCD
     int tile;
@@ -150,12 +193,23 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tstride = (int)gridDim.x;
+    // SK: logical workgroup Lw owns K steps [u0, u1) of the sequence (tile, k), tile = nt * ntiles_m + mt (column blocks outermost:
+    // the workgroups that walk the same rows of A for different column blocks are gridDim.x / ntiles_n block ids apart - a multiple
+    // of 8 for the grids the host picks, i.e. on one XCD at the same time)
+    const int Lw = SK ? (int)gridDim.x - 1 - (int)blockIdx.x : 0;
+    const int u0 = SK ? (int)((long long)Lw * p.sk_total / (int)gridDim.x) : 0;
+    const int u1 = SK ? (int)((long long)(Lw + 1) * p.sk_total / (int)gridDim.x) : 0;
+    auto tile_mn = [&](int T, int& mt, int& nt) {
+        if (SK) { nt = T / p.ntiles_m; mt = T - nt * p.ntiles_m; }
+        else    { mt = T / p.ntiles_n; nt = T - mt * p.ntiles_n; }
+    };
 
     // ---- staging cursors.  A: per-row byte offsets of this lane's MI rows in both sources (out of range past M);
     //      B: per-piece byte offsets of the weight rows of the tile's 256 columns (permuted, see the header)
     unsigned hoff1[MI], hoff2[DUAL ? MI : 1];
     auto a_tile = [&](int T) {
-        const int mt = T / p.ntiles_n;
+        int mt, nt_;
+        tile_mn(T, mt, nt_);
         const int m0 = mt * R;
         const int cells = p.Hout * p.Wout;
 #pragma unroll
@@ -178,7 +232,8 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     };
     unsigned wrow_off[NBD];
     auto b_tile = [&](int T) {
-        const int nt = T < p.ntiles ? T - (T / p.ntiles_n) * p.ntiles_n : 0;
+        int mt_ = 0, nt = 0;
+        if (T < p.ntiles) tile_mn(T, mt_, nt);
 #pragma unroll
         for (int d = 0; d < NBD; ++d) {
             const int P = d * 64 + wave * 8 + lr;
@@ -207,18 +262,24 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     // ---- prologue: A tiles of steps 0 and 1, B tile of step 0
     int ta = tile, ka = 0;          // A cursor: the step whose A tile is staged next (two ahead of the multiply)
     int tb = tile, kb = 0;          // B cursor (one ahead)
-    a_tile(ta);
+    int ua = u0;                    // SK: the A cursor's position in the step sequence; past u1 it stages nothing (out-of-range rows)
+    if (SK) { ta = u0 / nk; ka = u0 - ta * nk; tb = ta; kb = ka; }
+    a_tile(SK && u0 >= u1 ? p.ntiles : ta);
     b_tile(tb);
     unsigned a_st = 0, b_st = 0;    // ring slots the cursors stage into next (byte offsets)
 #define G8_ADV_A()                                                                                   \
     {                                                                                                \
         a_st = a_st == 2 * G8_STAGE ? 0u : a_st + G8_STAGE;                                          \
-        if (++ka == nk) { ka = 0; ta += tstride; a_tile(ta); }                                       \
+        if (SK) {                                                                                    \
+            ++ua;                                                                                    \
+            if (ua >= u1) { if (ua == u1) a_tile(p.ntiles); }                                        \
+            else if (++ka == nk) { ka = 0; ++ta; a_tile(ta); }                                       \
+        } else if (++ka == nk) { ka = 0; ta += tstride; a_tile(ta); }                                \
     }
 #define G8_ADV_B()                                                                                   \
     {                                                                                                \
         if (NW == 8) b_st ^= G8_STAGE; else b_st = b_st == 2 * BSTG ? 0u : b_st + BSTG;              \
-        if (++kb == nk) { kb = 0; tb += tstride; b_tile(tb); }                                       \
+        if (++kb == nk) { kb = 0; tb += SK ? 1 : tstride; b_tile(tb); }                              \
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -235,6 +296,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the LDS-DMA pieces and this wave's bias stores
     if (STAGGER && grp == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();                      // also publishes the bias table
+    G8_STAMP(1)
 
     unsigned a_cur = 0, b_cur = 0;                     // ring slots of the step being multiplied
     f32x4 acc[MI][NW];
@@ -258,12 +320,21 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_barrier();
 
-    while (tile < p.ntiles) {
-        const int mt = tile / p.ntiles_n, nt = tile - mt * p.ntiles_n;
+    int u = u0;                                        // SK: the next step of this workgroup's range
+    while (SK ? u < u1 : tile < p.ntiles) {
+        int k0 = 0, k1 = nk;                           // the K steps of this tile that this workgroup multiplies
+        if (SK) {
+            tile = u / nk;
+            k0 = u - tile * nk;
+            k1 = k0 + (u1 - u) < nk ? k0 + (u1 - u) : nk;
+        }
+        int mt, nt;
+        tile_mn(tile, mt, nt);
         const int m0 = mt * R, n0 = nt * CT;
         {
             const float* bp = bias_l + n0 + wn * (16 * NW) + NW * lrow;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + (NW == 8 ? 4 : 0));
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + (NW == 8 ? 4 : 0));
+            if (SK && k0 != 0) { b0 = (f32x4){0.f, 0.f, 0.f, 0.f}; b1 = b0; }     // not the tile's head: a plain partial sum
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -274,7 +345,7 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             }
         }
 #pragma unroll 1
-        for (int k = 0; k < nk; ++k) {
+        for (int k = k0; k < k1; ++k) {
             uint4 fa[MI], fb[4];
             if constexpr (NW == 4) {
                 // phase 1: fragments of k half 0, no staging (the stages freed by step k-1 may still be read by the lagging wave group)
@@ -321,8 +392,88 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
             b_cur ^= G8_STAGE;
             }
         }
+        // The leading wave group's closing barrier (it pairs with the lagging group's last K-loop barrier) comes BEFORE the last
+        // epilogue of the workgroup instead of after it: the lagging group's last epilogue then runs beside the leading group's, not
+        // behind it (nothing below touches the LDS rings or meets at a barrier again).
+        G8_STAMP(2)
+        if (STAGGER && grp == 0 && (SK ? u + (k1 - k0) >= u1 : tile + tstride >= p.ntiles)) __builtin_amdgcn_s_barrier();
+        G8_STAMP(3)
+        bool run_epilogue = true;
+        if constexpr (SK) {
+            u += k1 - k0;
+            constexpr unsigned SLOTS = MI * 4 * 2;                                 // 16-byte slots per thread of a partial tile
+            constexpr unsigned SLAB = SLOTS * G8_THREADS * 16u;                    // bytes per workgroup
+            const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)p.sk_slab, 0, (int)__builtin_amdgcn_readfirstlane((int)p.sk_slab_bytes), 0x00020000);
+            if (k0 != 0) {
+                // ---- a tail / middle piece of the tile: publish the partial sums (write-through), then the flag
+                const unsigned base = (unsigned)Lw * SLAB + (unsigned)t * 16u;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        u32x4 o0, o1;
+                        o0.x = __float_as_uint(acc[i][0][r]); o0.y = __float_as_uint(acc[i][1][r]); o0.z = __float_as_uint(acc[i][2][r]); o0.w = __float_as_uint(acc[i][3][r]);
+                        o1.x = __float_as_uint(acc[i][4][r]); o1.y = __float_as_uint(acc[i][5][r]); o1.z = __float_as_uint(acc[i][6][r]); o1.w = __float_as_uint(acc[i][7][r]);
+                        const unsigned slot = (unsigned)((i * 4 + r) * 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(o0, slab_rsrc, (int)(base + slot * (G8_THREADS * 16u)), 0, 16);            // aux 16 = sc1
+                        RTN_STORE_GUARD(o0)
+                        __builtin_amdgcn_raw_buffer_store_b128(o1, slab_rsrc, (int)(base + (slot + 1) * (G8_THREADS * 16u)), 0, 16);
+                        RTN_STORE_GUARD(o1)
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // EVERY storing wave drains before the flag may go up
+                // ... and says so in LDS; the wave whose add comes last raises the flag.  No barrier: the two wave groups keep their offset
+                // and the leading group goes straight on to the next tile's steps.
+                unsigned arrived = 0;
+                if (lane == 0) arrived = __hip_atomic_fetch_add(sk_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0 && arrived == (unsigned)(G8_THREADS / 64 - 1))
+                    __hip_atomic_store(p.sk_flags + Lw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run_epilogue = false;
+            } else if (k1 != nk) {
+                // ---- the head of a tile whose other pieces belong to workgroups Lw + 1 .. Lw + np (lower block ids): wait, add in K order
+                const int tile_end = (tile + 1) * nk, G = (int)gridDim.x;
+                int np = 0;
+                while (Lw + 1 + np < G && (int)((long long)(Lw + 1 + np) * p.sk_total / G) < tile_end) ++np;
+                if (wave == 0) {
+                    unsigned* f = p.sk_flags + Lw + 1 + lane;
+                    bool pending = lane < np;
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                    while (__builtin_amdgcn_ballot_w64(pending) != 0ull) {
+                        if (pending && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) pending = false;
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > 200000000ull) {       // 2 s at 100 MHz: give up, count it, go on
+                            if (pending) __hip_atomic_fetch_add(p.sk_flags + SK_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (lane < np) __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // clean for the next launch
+                    if (lane == 0) __hip_atomic_store(sk_sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    while (__hip_atomic_load(sk_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // (no instruction: keeps the slab loads below the poll / the LDS word)
+                __builtin_amdgcn_sched_barrier(0);
+                for (int qn = 1; qn <= np; ++qn) {
+                    const unsigned base = (unsigned)(Lw + qn) * SLAB + (unsigned)t * 16u;
+                    // one row fragment at a time (8 x 16 B per lane in flight): the registers of a second batch would spill
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        u32x4 buf[8];
+#pragma unroll
+                        for (int s8 = 0; s8 < 8; ++s8)
+                            buf[s8] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, (int)(base + (unsigned)(i * 8 + s8) * (G8_THREADS * 16u)), 0, 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                acc[i][j][r] += __uint_as_float(buf[r * 2 + (j >> 2)][j & 3]);
+                    }
+                }
+            }
+        }
+        G8_STAMP(4)
         // ---- epilogue: [mask] [+ residual] [mask] ReLU, bf16, 4 MI stores of 16 B per lane
-        {
+        if (run_epilogue) {
             const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)p.out, 0, (int)__builtin_amdgcn_readfirstlane((int)p.out_bytes), 0x00020000);
             const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -413,7 +564,8 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
                 }
             }
         }
-        tile += tstride;
+        G8_STAMP(5)
+        if (!SK) tile += tstride;
     }
 #undef G8_MFMA
 #undef G8_LDB
@@ -421,14 +573,18 @@ __global__ __launch_bounds__(G8_THREADS, 2) void conv_gemm8_kernel(const G8Param
 #undef G8_ADV_B
 #undef G8_ADV_A
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
-    if (STAGGER && grp == 0) __builtin_amdgcn_s_barrier();
+    G8_STAMP(6)
 }
 
 }  // namespace
 
 // Launcher: RTN_OK after a launch, 1 when the layer is not one this kernel takes, < 0 on error.
+// `sync` / `ws` / `ws_cap`: the caller-owned workspace of the stream-K form - its 4-KiB sync block (zero before and after every launch)
+// and the slab area behind it; `query` != nullptr: no launch, *query = slab bytes this layer would use (0: no stream-K for it).
+// `sk_mode`: -1 = cost model, 0 = never, 1 = wherever the shape allows (tests, A/B).
 int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2, int grid_limit, bool stagger, bool forced,
-                       int mi_force) {
+                       int mi_force, unsigned* sync, void* ws, long long ws_cap, size_t* query, int sk_mode) {
+    if (query) *query = 0;
     if (d->dtype != RTN_BF16 || d->ngroups != 1) return 1;
     if (d->KH != 1 || d->KW != 1 || d->pad_t != 0 || d->pad_l != 0 || d->sy != d->sx || d->sy < 1 || d->sy > 2) return 1;
     if (d->flags & ~(RTN_CONV_RELU | RTN_CONV_RES_SAME | RTN_CONV_RES_UPSAMPLE | RTN_CONV_RELU_MASK | RTN_CONV_MASK_PRE)) return 1;
@@ -506,23 +662,68 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (Kbytes > 16384 || Kbytes * d->N >= (long long)G8_OOB) return 1;
     const int cus = h->num_cus > 0 ? h->num_cus : 256;
     const int ntn = n128 ? 1 : (d->N + 255) / 256;         // N = 128: the 128-column instance, one column tile
+    const long long nk_all = Kbytes / 128;
     int mi = mi_force;
-    if (mi < 2 || mi > 3) {                            // tile height by rounds x (rows + a fixed per-tile cost)
+    double plain_cost = 0;                             // in units of one 64-row fragment row x one K step
+    {                                                  // tile height by rounds x K steps x (rows + a fixed per-step cost)
         double best = 0;
+        int pick = 0;
         for (int cand = 3; cand >= 2; --cand) {
+            if (mi_force >= 2 && mi_force <= 3 && cand != mi_force) continue;
             const long long tl = ((M + 64 * cand - 1) / (64 * cand)) * ntn;
             const double cost = (double)((tl + cus - 1) / cus) * (cand + 0.4);
-            if (cand == 3 || cost < best * 0.97) { best = cost; mi = cand; }
+            if (pick == 0 || cost < best * 0.97) { best = cost; pick = cand; }
         }
+        mi = pick;
+        plain_cost = best * (double)nk_all;
+    }
+    // Stream-K: every workgroup an equal share of the tiles x K steps (see the header).  Taken when it saves at least TEN K steps per
+    // workgroup against whole rounds of whole tiles - measured at batch 8, 800 x 1333 (profiles/r4_streamk_gemm8.txt): the hand-off costs
+    // 8-10 us whatever the layer (every workgroup publishes one partial tile and owns one: 50 MB out and back at the end of the launch,
+    // all owners at once), and a K step does not stay 1.25 us when more CUs run it - between 175 and 256 busy CUs it grows to 1.6-1.9 us
+    // (shader clock 2.08 -> 2.01 GHz only; the staging rate of the chip, 8-9 TB/s L2 -> LDS, is the same in both cases).  So the layers
+    // with 175 of 256 tiles (stage 4, C4_reduced: 5 steps saved) LOSE 4-7 us, and the ones on 44-88 CUs (stage 5 branch2a 21 steps,
+    // C5_reduced 26, res5a branch2c + shortcut 15) gain 6-15 us.  Grid: the CUs, at most 8 pieces per tile.
+    int sk_grid = 0;
+    const bool sk_shape = !n128 && !(epi & 2) && !scatter && stagger && nk_all >= 2 && nk_all <= 256;
+    if (sk_shape && sk_mode != 0 && (query || (sync && ws && !((uintptr_t)ws & 15) && !((uintptr_t)sync & 15)))) {
+        double best = 0;
+        int pick = 0, pick_grid = 0;
+        for (int cand = 3; cand >= 2; --cand) {
+            if (mi_force >= 2 && mi_force <= 3 && cand != mi_force) continue;
+            const long long tl = ((M + 64 * cand - 1) / (64 * cand)) * ntn, total = tl * nk_all;
+            long long G = cus;
+            if (grid_limit > 0 && grid_limit < G) G = grid_limit;
+            if (G > tl * 8) G = tl * 8;
+            if (G > total) G = total;
+            if (G > SK_ERR_WORD) G = SK_ERR_WORD;
+            if (G < 1 || total >= (1ll << 30)) continue;
+            const long long slab_need = G * (long long)(cand * 4 * 2) * G8_THREADS * 16;
+            if (!query && slab_need > ws_cap) continue;
+            if (slab_need >= (long long)G8_OOB) continue;
+            const long long share_i = (total + G - 1) / G;
+            const double share = (double)share_i;
+            const bool whole = total % G == 0 && share_i % nk_all == 0;               // every range = whole tiles: nothing is handed over
+            const double partners = (double)((nk_all + share_i - 1) / share_i);      // pieces the longest-cut tile has besides its head
+            const double fix = whole ? 0.0 : 10.0 + 2.0 * (partners > 2.0 ? partners - 2.0 : 0.0);
+            const double cost = (share + fix) * (cand + 0.4);
+            if (pick == 0 || cost < best * 0.97) { best = cost; pick = cand; pick_grid = (int)G; }
+        }
+        if (pick && (sk_mode > 0 || best <= plain_cost)) { mi = pick; sk_grid = pick_grid; }
     }
     const long long ntm = (M + 64 * mi - 1) / (64 * mi), tiles = ntm * ntn;
     if (tiles > 0x3fffffff) return 1;
+    if (query) {
+        if (!sk_grid) return 1;                        // nothing to reserve: the caller's other paths answer the query
+        *query = (size_t)sk_grid * (size_t)(mi * 4 * 2) * G8_THREADS * 16;
+        return RTN_OK;
+    }
     // too few tiles to be worth one workgroup per CU: below ~5/8 of the chip the 64-wide tiles of generation 2 (four times the
     // workgroups) win (res5 branch2a, 132 tiles: 0.049 ms here against 0.043; C5_reduced, 66 tiles: 0.046 against 0.041), above
     // it this kernel does (res4 branch2a, 175 tiles: 0.037 against 0.046).  (Round 3 re-measured: back-to-back launches of ONE layer
     // say the opposite for res5 branch2a - 0.034 against 0.039 - because its 2 MB of filters then sit in the L2; in the step's own
     // sequence, tools/profile_layers.py, it is 0.049 against 0.046-0.047 as before.  Judge such layers in sequence.)
-    if (!forced && tiles * 8 < cus * 5) return 1;
+    if (!forced && !sk_grid && tiles * 8 < cus * 5) return 1;
     p.w = (const char*)d->w;
     p.bias = d->bias;
     p.out = (char*)g.out;
@@ -548,6 +749,29 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;
+    if (sk_grid) {
+        grid = sk_grid;
+        p.sk_total = (int)(tiles * nk_all);
+        p.sk_slab = (char*)ws;
+        p.sk_slab_bytes = (unsigned)((size_t)sk_grid * (size_t)(mi * 4 * 2) * G8_THREADS * 16);
+        p.sk_flags = sync;
+    }
+#define RTN_G8_LAUNCH_SK(M_, DU, EP)                                                                     \
+    do {                                                                                                 \
+        static bool attr_set = false;                                                                    \
+        if (!attr_set) {                                                                                 \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, true, DU, EP, 8, true>,    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
+            attr_set = true;                                                                             \
+        }                                                                                                \
+        hipLaunchKernelGGL((conv_gemm8_kernel<M_, true, DU, EP, 8, true>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
+    } while (0)
+#define RTN_G8_PICK_SK(M_)                                                                               \
+    do {                                                                                                 \
+        if (s2) RTN_G8_LAUNCH_SK(M_, true, 0);                                                           \
+        else if (epi == 0) RTN_G8_LAUNCH_SK(M_, false, 0);                                               \
+        else RTN_G8_LAUNCH_SK(M_, false, 1);                                                             \
+    } while (0)
 #define RTN_G8_LAUNCH(M_, ST, DU, EP)                                                                    \
     do {                                                                                                 \
         static bool attr_set = false;                                                                    \
@@ -583,12 +807,22 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         else if (epi == 2) RTN_G8_LAUNCH4(M_, 2); else RTN_G8_LAUNCH4(M_, 3);                            \
     } while (0)
     const bool narrow = n128 && !s2 && stagger && rtn_env_int("RTN_CONV_G8_NARROW", 1) != 0;      // 0: N = 128 on the 256-column tile (A/B)
-    if (narrow) { if (mi == 3) RTN_G8_PICK4(3); else RTN_G8_PICK4(2); }
+    if (sk_grid) { if (mi == 3) RTN_G8_PICK_SK(3); else RTN_G8_PICK_SK(2); }
+    else if (narrow) { if (mi == 3) RTN_G8_PICK4(3); else RTN_G8_PICK4(2); }
     else if (mi == 3) RTN_G8_PICK(3); else RTN_G8_PICK(2);
+#undef RTN_G8_PICK_SK
+#undef RTN_G8_LAUNCH_SK
 #undef RTN_G8_PICK4
 #undef RTN_G8_LAUNCH4
 #undef RTN_G8_PICK
 #undef RTN_G8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_gemm8_kernel");
+    h->last_conv_streamk = sk_grid;
     return RTN_OK;
 }
+
+#ifdef RTN_G8_STAMP
+extern "C" int rtn_debug_g8_stamps(unsigned long long* out8192) {
+    return (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(g_g8_stamps), sizeof(unsigned long long) * 8192, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -11,6 +11,7 @@ struct rtn_ctx {
     hipStream_t stream;
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
     int num_cus;
+    int last_conv_streamk;        // rtn_debug_last_conv_streamk: workgroups of the last conv launch if it ran in stream-K form, else 0
     int last_conv_impl;
          // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
     int last_wgrad_impl;          // rtn_debug_last_wgrad_impl: 2 = 256x256 LDS-DMA, 3 = 128x128 LDS-DMA, 4 = rtn_wgrad_win.hip, 0 = register-staged
@@ -62,7 +63,7 @@ int rtn_conv_ksplit_finish(rtn_handle_t h, const float* slab, int S, long long M
 // rtn_conv_gemm8.hip: the same schedule as a plain GEMM for the 1x1 layers with N % 256 == 0 and a bias / ReLU epilogue, one or
 // two (K-concatenated) sources, stride 1 or 2.
 int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_src2_t* s2, int grid_limit, bool stagger, bool forced,
-                       int mi_force);
+                       int mi_force, unsigned* sync, void* ws, long long ws_cap, size_t* query, int sk_mode);
 int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit, bool forced);
 
 static inline int rtn_dtype_size(int dt) { return dt == RTN_F32 ? 4 : (dt == RTN_FP8 ? 1 : 2); }

@@ -81,6 +81,16 @@ class Engine:
         self.anchor_params = anchor_params or AnchorParams()
         self.w = {}
         self.plans = {}
+        # A plan owns every activation buffer, descriptor and workspace of one (batch, canvas): several GB at the benchmark sizes.
+        # csv_generator.compute_inputs pads each batch to ITS largest page, so a data set with varied page shapes shows a new canvas
+        # nearly every step: the cache keeps the `max_plans` most recently used canvases and frees the rest (RTN_MAX_PLANS).
+        self.max_plans = max(1, int(os.environ.get("RTN_MAX_PLANS", "4")))
+        # detect() with `in_flight` > 1: consecutive batches run on `in_flight` buffer sets, each on ONE HIP stream of its own, so the
+        # next batch's backbone fills the CUs the current batch's small-M layers and kernel tails leave idle (see detect()).
+        self.in_flight = 1
+        self.trace_in_flight = None
+        self._slots, self._next_slot = [], 0
+        self.on_plan_evict = []        # weakref.WeakMethod callbacks key -> None (a Trainer drops its backward plan of the same canvas)
         self.state = None
         self.training = False          # set by trainer.Trainer: the pool then records its argmax taps
         self.two_streams = os.environ.get("RTN_TWO_STREAMS", "1") != "0"    # graph forks on side HIP streams (_schedule)
@@ -106,6 +116,9 @@ class Engine:
         """state: Keras-named dict (see weights.py). Packs every conv (BN folded) into ONE flat device buffer of
         forward weights (dtype of the path) and one flat f32 bias buffer; per-layer tensors are views into them, so an
         optimizer can rewrite all weights with a single kernel (trainer.py)."""
+        if any(s["done"] is not None for s in self._slots):
+            torch.cuda.synchronize(self.device)          # batches in flight read the buffers released below
+        self._slots, self._next_slot = [], 0
         self.state = state
         self.w = {}
         self.layout = {}
@@ -298,6 +311,7 @@ class Engine:
         s2.in_, s2.in_elems = x.data_ptr(), x.numel()
         s2.in_img_stride, s2.in_row_stride, s2.pix_stride = x.shape[1] * x.shape[2] * x.shape[3], x.shape[2] * x.shape[3], x.shape[3]
         s2.Hin, s2.Win, s2.C, s2.step = x.shape[1], x.shape[2], x.shape[3], fb["step"]
+        L.attach_conv_workspace(self.h, d, s2)             # stream-K slabs of the small-M stages (res5a): caller-owned
         return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
     def _bneck_proj_op(self, fb, B, keep_h1=False):
@@ -345,13 +359,25 @@ class Engine:
         return ("bneck", d, name, {"xs": [a, x], "ys": outs, "B": B, "H": blk["Ho"], "W": blk["Wo"], "tail": nxt is not None, "h1": keep_h1})
 
     # ------------------------------------------------------------------ plan
-    def _plan(self, B, H, W):
+    def _plan(self, B, H, W, slot=0):
         fp8_on = self._fp8_on()
-        key = (B, H, W, fp8_on)
+        key = (B, H, W, fp8_on) if slot == 0 else (B, H, W, fp8_on, slot)      # slot: buffer set of a batch in flight (detect())
         if key in self.plans:
+            self.plans[key] = self.plans.pop(key)          # most recently used last
             return self.plans[key]
         if self.state is None:
             raise RuntimeError("load_state() first")
+        if len(self.plans) >= self.max_plans:
+            # least recently used canvases go.  Their buffers may still be read by launches in flight on the side streams, and the
+            # caching allocator would hand the memory to this plan's tensors on the current stream: drain the device first (a new
+            # canvas costs a plan build anyway).
+            torch.cuda.synchronize(self.device)
+            while len(self.plans) >= self.max_plans:
+                old = next(iter(self.plans))
+                self.on_plan_evict = [r for r in self.on_plan_evict if r() is not None]     # weak references to bound methods
+                for r in self.on_plan_evict:
+                    r()(old)
+                del self.plans[old]
         dev, tdt = self.device, self.tdt
         ops, keep = [], []
 
@@ -782,19 +808,136 @@ class Engine:
 
     def detect(self, images, score_threshold=0.05, nms_threshold=0.5, max_detections=300):
         """Inference model outputs [boxes (B,300,4), scores (B,300), labels (B,300)] (model/defineModel.py:310-315).
-        Views of the plan's output buffers: overwritten by the next call with the same (B,H,W) - clone to keep them."""
-        reg, cls = self.forward(images)
-        B, H, W, _ = images.shape
-        plan = self._plan(B, H, W)
+        Views of the plan's output buffers: overwritten by the next call with the same (B,H,W) - clone to keep them.
+
+        in_flight > 1 (throughput mode; default 1): the call enqueues this batch on the next of `in_flight` buffer sets and returns at
+        once; batches of consecutive calls then overlap on the device (separate HIP streams, one per buffer set: stage-4/5 layers
+        use 44-175 of 256 CUs and every kernel has a tail - the neighbouring batch's kernels run there; measured 4.07 -> 3.57 ms per
+        batch of 8 at 800x1333, profiles/r4_in_flight.txt).  The page tensor is consumed in the caller's stream order (the stem packer
+        runs on the caller's stream), so it may be overwritten as soon as the call returns.  The returned views belong to the buffer
+        set: valid after join() (or any device synchronisation) and until the in_flight-th call after this one."""
         md = int(max_detections)
         if not 1 <= md <= L.RTN_MAX_DET:
             raise ValueError("max_detections must be in [1, %d]" % L.RTN_MAX_DET)
+        if self.in_flight > 1 and not self.training:
+            return self._detect_in_flight(images, score_threshold, nms_threshold, md)
+        reg, cls = self.forward(images)
+        B, H, W, _ = images.shape
+        plan = self._plan(B, H, W)
         # the library writes (B, max_detections, .) densely: hand it views of that shape over the plan's buffers
         boxes = plan["boxes"].view(-1)[:B * md * 4].view(B, md, 4)
         scores = plan["scores"].view(-1)[:B * md].view(B, md)
         labels = plan["labels"].view(-1)[:B * md].view(B, md)
         self.postprocess(plan["cfg"], reg, cls, H, W, boxes, scores, labels, plan["det_ws"], score_threshold, nms_threshold, md)
         return boxes, scores, labels
+
+    def _detect_in_flight(self, images, score_threshold, nms_threshold, md):
+        if images.device.type != "cuda" or images.dim() != 4 or images.shape[3] != 3:
+            raise ValueError("images must be a (B,H,W,3) tensor on the GPU")
+        if images.dtype not in _SRC_DT:
+            raise ValueError("unsupported image dtype %s" % images.dtype)
+        images = images.contiguous()
+        B, H, W, _ = images.shape
+        if len(self._slots) != self.in_flight:
+            self.join()
+            self._slots = [{"stream": st_, "done": None, "fed": torch.cuda.Event()} for st_ in self._concurrent_streams(self.in_flight)]
+            self._next_slot = 0
+        si = self._next_slot
+        self._next_slot = (si + 1) % self.in_flight
+        slot = self._slots[si]
+        if self._fp8_on() and self._w8_version != self.weights_version:
+            self.join()
+            self.plans = {k: v for k, v in self.plans.items() if not k[3]}
+        plan = self._plan(B, H, W, slot=si + 1)             # slot 0 is forward()'s / the one-batch path's own buffer set
+        fused = self._fused()
+        ops = plan["variants"][fused][0] if fused else plan["ops"]
+        caller = torch.cuda.current_stream(self.device)
+        if fused and fused[1] and self._dual_version != self.weights_version:
+            self.join()                                       # new weights: the concatenated filters are rewritten on the caller's
+            self._dual_weights()                              # stream - nothing may be in flight on the old ones, and the batches
+            caller.synchronize()                              # that follow on other streams must see the new ones
+        if slot.get("consumed") is not None:
+            # the packer below rewrites this buffer set's packed image: its previous batch must have read it (the stem, that batch's
+            # first kernel on the slot's stream).  NOT the whole previous batch: that would chain the slots through the caller's
+            # stream and keep the batches in lockstep (measured: no overlap at all with two in flight, profiles/r4_in_flight.txt)
+            caller.wait_event(slot["consumed"])
+        self.h.set_stream(caller.cuda_stream)
+        first = 0
+        if ops and ops[0][0] == "pack":                      # the only reader of `images`: in the caller's stream order
+            self._run_op(ops[0], images)
+            first = 1
+        else:
+            images = images.clone()                          # (paths without the packer: a private copy, made in the caller's order)
+        slot["fed"].record(caller)
+        st = slot["stream"]
+        st.wait_event(slot["fed"])
+        # (Staggering the batches by stage - a batch's backbone behind the previous batch's backbone, its towers behind the previous
+        # towers - was measured too and is WORSE than letting the slots' streams drift: 4.27 against 3.55 ms with three in flight.)
+        with torch.cuda.stream(st):
+            self.h.set_stream(st.cuda_stream)
+            if self.trace_in_flight is not None:             # tools/exp_in_flight_engine.py: (slot, start, end) timing events per batch
+                t_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                t_ev[0].record(st)
+            for i in range(first, len(ops)):
+                self._run_op(ops[i], images)
+                if i == first:
+                    slot["consumed"] = torch.cuda.Event()
+                    slot["consumed"].record(st)
+            if first == 0:
+                images.record_stream(st)                     # the private copy is read on the slot's stream
+            boxes = plan["boxes"].view(-1)[:B * md * 4].view(B, md, 4)
+            scores = plan["scores"].view(-1)[:B * md].view(B, md)
+            labels = plan["labels"].view(-1)[:B * md].view(B, md)
+            self.postprocess(plan["cfg"], plan["regression"], plan["classification"], H, W, boxes, scores, labels, plan["det_ws"],
+                             score_threshold, nms_threshold, md)
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(st)
+            if self.trace_in_flight is not None:
+                t_ev[1].record(st)
+                self.trace_in_flight.append((si, t_ev[0], t_ev[1]))
+        self.h.set_stream(caller.cuda_stream)
+        return boxes, scores, labels
+
+    def _concurrent_streams(self, n):
+        """n HIP streams whose kernels really run beside each other.  The runtime multiplexes HIP streams onto a few hardware queues
+        (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one are served strictly in turn: batches "in flight" on such a
+        pair do not overlap at all (measured: 4.28 against 3.60 ms per batch, and WHICH streams of torch's pool collide changes with
+        the streams created before; profiles/r4_in_flight.txt).  So candidates are tested, once: a one-workgroup spin kernel
+        (torch.cuda._sleep) on the candidate and on every stream already chosen must take the time of one, not of two."""
+        sleep = getattr(torch.cuda, "_sleep", None)
+        chosen = []
+        if sleep is None:
+            return [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        import time
+        cycles = 400000
+
+        def spin(streams):
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for st_ in streams:
+                with torch.cuda.stream(st_):
+                    sleep(cycles)
+            for st_ in streams:
+                st_.synchronize()
+            return time.perf_counter() - t0
+        for _ in range(8 * n):
+            if len(chosen) == n:
+                break
+            cand = torch.cuda.Stream(device=self.device)
+            spin([cand])                                             # first use of a stream: not timed
+            one = min(spin([cand]) for _ in range(2))
+            if all(min(spin([cand, c]) for _ in range(2)) < 1.5 * one for c in chosen):
+                chosen.append(cand)
+        while len(chosen) < n:                                       # (no overlapping set found: the batches still run, one queue at a time)
+            chosen.append(torch.cuda.Stream(device=self.device))
+        return chosen
+
+    def join(self):
+        """The caller's current stream waits for every batch detect() has in flight (in_flight > 1)."""
+        cur = torch.cuda.current_stream(self.device)
+        for slot in self._slots:
+            if slot["done"] is not None:
+                cur.wait_event(slot["done"])
 
     def postprocess(self, cfg, regression, classification, H, W, boxes, scores, labels, ws, score_threshold=0.05,
                     nms_threshold=0.5, max_detections=300):

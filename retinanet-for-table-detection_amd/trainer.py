@@ -20,6 +20,8 @@ import ctypes as C
 
 import numpy as np
 import os
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -45,7 +47,14 @@ class Trainer:
         self._wg_stream = None
         self.record_impls = False      # tests: {(kind, layer): kernel code} of the last backward (rtn_debug_last_*_impl)
         self.impls = {}
+        # a backward plan holds gradient buffers, descriptors into the forward plan's activations and every weight-gradient workspace
+        # (row-info table + split slabs: GBs per canvas): it lives exactly as long as the engine's plan of the same canvas
+        engine.on_plan_evict.append(weakref.WeakMethod(self._drop_bplan))
         self._bind_engine_state()
+
+    def _drop_bplan(self, plan_key):
+        if len(plan_key) == 4:                              # (B, H, W, fp8): the one-batch buffer set the backward plan points into
+            self.bplans.pop(tuple(plan_key[:3]), None)
 
     def _bind_engine_state(self):
         """Everything derived from the engine's loaded state: the f32 master copy, fold / gradient scales, Adam moments, dgrad
@@ -156,10 +165,11 @@ class Trainer:
     # ------------------------------------------------------------------ backward plan
     def _bplan(self, B, H, W):
         key = (B, H, W)
-        if key in self.bplans:
-            return self.bplans[key]
         eng = self.eng
-        plan = eng._plan(B, H, W)
+        if key in self.bplans:
+            eng._plan(B, H, W)                             # marks the canvas as recently used in the engine's cache
+            return self.bplans[key]
+        plan = eng._plan(B, H, W)                          # may evict the least recently used canvas: _drop_bplan() follows
         dev, tdt, rdt = eng.device, eng.tdt, eng.rdt
         ops = plan["ops"]
         keep, bops = [], []
@@ -557,6 +567,7 @@ class Trainer:
             raise RuntimeError("Engine.load_state() ran between forward_backward() and optimizer_step(): the gradient belongs to "
                                "the previous weights")
         eng, lib, h = self.eng, L.lib, self.eng.h
+        eng.join()                                   # inference batches still in flight (Engine.in_flight > 1) read the weights rewritten below
         eng._bind_stream()
         if self.bucketer is not None:                # sum of per-rank gradients == gradient of the merged batch
             self.bucketer.finish()

@@ -48,15 +48,27 @@ def pack_w(w_hwio, dtype, dev):
     return wk.to(DT[dtype][0]).to(dev).contiguous(), rows
 
 
+LAST = {}                                          # the last run_case's descriptor / workspace (stream-K checks)
+
+
 def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res_mode=None, B=2, seed=0, out_ld=None,
-             concat=False, reference=True):
-    """levels: list of (H, W). Returns (got list, want list) per level (f64, NHWC)."""
+             concat=False, reference=True, exact=False):
+    """levels: list of (H, W). Returns (got list, want list) per level (f64, NHWC).
+    exact: small-integer operands - every product and every partial sum is exact in f32 whatever the order of the additions, so two
+    kernels that split the K loop differently must agree bit for bit with each other and with the float64 reference."""
     L = pkg._lib
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(seed)
     tdt = DT[dtype][0]
-    w = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin)
-    bias = torch.randn(cout, generator=g, dtype=torch.float64)
+    randn = torch.randn
+    if exact:
+        def randn(*shape, generator=None, dtype=None):
+            return torch.randint(-3, 4, shape, generator=generator).to(dtype)
+        w = torch.randint(-2, 3, (k, k, cin, cout), generator=g).double()
+        bias = torch.randint(-8, 9, (cout,), generator=g).double()
+    else:
+        w = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / math.sqrt(k * k * cin)
+        bias = torch.randn(cout, generator=g, dtype=torch.float64)
     wq = q(w, dtype)
     wk, rows = pack_w(w, dtype, dev)
     bk = torch.zeros(rows, dtype=torch.float32)
@@ -79,7 +91,7 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
         keep.append(big)
     off = 0
     for gi, (H, W) in enumerate(levels):
-        x = torch.randn(B, H, W, cin, generator=g, dtype=torch.float64)
+        x = randn(B, H, W, cin, generator=g, dtype=torch.float64)
         if pad == "same":
             Ho, Wo = -(-H // stride), -(-W // stride)
             pt = max((Ho - 1) * stride + k - H, 0) // 2
@@ -95,11 +107,11 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
         grp.in_img_stride, grp.in_row_stride = H * W * cin, W * cin
         grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, Ho, Wo
         if res_mode == "same":
-            r = torch.randn(B, Ho, Wo, cout, generator=g, dtype=torch.float64)
+            r = randn(B, Ho, Wo, cout, generator=g, dtype=torch.float64)
             want = want + q(r, dtype)
         elif res_mode == "up":
             rh, rw = max(1, (Ho + 1) // 2), max(1, (Wo + 1) // 2 + (gi % 2))
-            r = torch.randn(B, rh, rw, cout, generator=g, dtype=torch.float64)
+            r = randn(B, rh, rw, cout, generator=g, dtype=torch.float64)
             want = want + upsample_nearest_legacy(q(r, dtype), Ho, Wo)
         if res_mode:
             rd = r.to(tdt).to(dev).contiguous()
@@ -126,9 +138,10 @@ def run_case(pkg, handle, dtype, levels, cin, cout, k, stride, pad, flags=0, res
         keep.append(xd)
         wants.append(want)
     d.flags = flags
-    L.attach_conv_workspace(handle, d)            # the split-K / tail-split paths take their slabs from the caller
+    L.attach_conv_workspace(handle, d)            # the split-K / tail-split / stream-K paths take their slabs from the caller
     handle.check(L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
+    LAST["d"], LAST["keep"] = d, keep
     gots = []
     for o, want in zip(outs, wants):
         if concat:
@@ -293,6 +306,64 @@ def test_persistent_gemm8_kernel(pkg, handle, monkeypatch, levels, cin, cout, st
         assert float((a - b).abs().max()) <= 4e-2 * max(1.0, float(b.abs().max()))
 
 
+def sk_timeouts(pkg, handle):
+    """Bounded flag polls of the last run_case's launch that gave up (the error word of its workspace's sync block)."""
+    L = pkg._lib
+    n = C.c_uint32(123)
+    handle.check(L.lib.rtn_debug_conv_sync_timeouts(handle.raw, LAST["d"].workspace, C.byref(n)))
+    return int(n.value)
+
+
+@pytest.mark.parametrize("levels,cin,cout,stride,res,B,grid,mi", [
+    ([(25, 42)], 2048, 512, 1, None, 2, 0, 0),     # res5 branch2a-like: 22 tiles x 32 K steps on 176 workgroups, 8 pieces per tile
+    ([(25, 42)], 2048, 512, 1, None, 2, 7, 3),     # ... 7 workgroups: every range = tail of a tile + whole tiles + head of the next
+    ([(25, 42)], 1024, 256, 1, "up", 3, 0, 3),     # C4_reduced-like: upsampled residual in the owner's epilogue
+    ([(33, 50)], 128, 512, 1, "same", 2, 5, 2),    # branch2c + shortcut, two K steps per tile, 128-row tiles
+    ([(33, 50)], 512, 512, 2, None, 2, 6, 2),      # stride-2 'valid' source
+    ([(5, 7)], 1024, 256, 1, None, 1, 0, 3),       # ONE partly filled tile cut into 8 pieces of 2 K steps
+    ([(40, 67)], 1024, 1024, 1, "same", 1, 0, 0),  # res4 branch2c-like: 4 column blocks, more tiles than a grid would need - the cost model's choice, forced
+    ([(17, 23)], 256, 256, 1, None, 3, 3, 2),      # 4 K steps, 10 tiles on 3 workgroups: range boundaries at 13.3 and 26.7 steps
+])
+def test_gemm8_stream_k(pkg, handle, monkeypatch, levels, cin, cout, stride, res, B, grid, mi):
+    """The stream-K form of generation 5 (RTN_CONV_G8_SK=1: wherever the shape allows): tiles x K steps cut into equal ranges, tails
+    handed to the tile's owner through sc1 slabs + flags inside the launch.  (a) small-integer operands: BIT-IDENTICAL to the unsplit
+    kernel and to the float64 reference (every sum is exact, so only a lost / doubled / misplaced piece can differ); (b) random
+    operands: within the bf16 tolerance of float64 and of the unsplit kernel, and the same bits on every launch (fixed order of the
+    adds); no poll timed out; the sync block is clean again (the second launch on the SAME workspace works)."""
+    L = pkg._lib
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    monkeypatch.setenv("RTN_CONV_G8_MI", str(mi))
+    flags = (L.CONV_RES_SAME if res == "same" else 0) | (L.CONV_RES_UPSAMPLE if res == "up" else 0) | (0 if res == "up" else L.CONV_RELU)
+    out = {}
+    for sk in ("1", "0"):
+        monkeypatch.setenv("RTN_CONV_G8_SK", sk)
+        for exact in (True, False):
+            gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, cin, cout, 1, stride, 0, flags, res, B=B, seed=300 + grid, exact=exact)
+            assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+            assert (L.lib.rtn_debug_last_conv_streamk(handle.raw) > 0) == (sk == "1")
+            if sk == "1":
+                assert sk_timeouts(pkg, handle) == 0
+                d = LAST["d"]                              # once more on the same workspace: the owner left the flags at zero
+                handle.check(L.lib.rtn_conv2d_fwd(handle.raw, C.byref(d)))
+                assert sk_timeouts(pkg, handle) == 0
+            if exact:
+                for a, b in zip(gots, wants):
+                    assert torch.equal(a[..., :n], q(b, "bf16")), "exact operands: %.3e off the float64 result" % float((a[..., :n] - b).abs().max())
+            else:
+                check(gots, wants, ld, n, "bf16")
+            out[(sk, exact)] = gots
+    for a, b in zip(out[("1", True)], out[("0", True)]):
+        assert torch.equal(a, b)
+    for a, b in zip(out[("1", False)], out[("0", False)]):
+        assert float((a - b).abs().max()) <= 8e-3 * max(1.0, float(b.abs().max()))           # one bf16 ulp where the f32 sums round apart
+    monkeypatch.setenv("RTN_CONV_G8_SK", "1")
+    for _ in range(2):
+        again, _, _, _ = run_case(pkg, handle, "bf16", levels, cin, cout, 1, stride, 0, flags, res, B=B, seed=300 + grid, reference=False)
+        for a, b in zip(again, out[("1", False)]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("levels,cin,cout,B,grid,mi,ksplit", [
     ([(25, 42)], 512, 512, 2, 0, 0, 0),       # res5 branch2b: two column blocks; tile height and K slices by the cost model
     ([(25, 42)], 512, 512, 2, 3, 4, 1),       # ... unsliced: the epilogue adds the bias (accumulators of a block item start at zero)
@@ -371,15 +442,15 @@ def test_gemm8_narrow_instance_for_128_columns(pkg, handle, monkeypatch, levels,
 
 
 def test_persistent_8phase_kernel_repeats_bit_for_bit(pkg, handle, monkeypatch):
-    """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 12 launches of a
+    """A race between an LDS-DMA piece and a fragment read shows up as a tile that changes from launch to launch: 6 launches of a
     head-tower-sized layer (five levels, 700 tiles, every CU walking 2-3 of them) must give the same bits, staggered and not."""
     L = pkg._lib
     monkeypatch.setenv("RTN_CONV_IMPL", "4")
     levels = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
     first = None
-    for it in range(12):
+    for it in range(6):
         monkeypatch.setenv("RTN_CONV_H8_STAGGER", str(1 - it % 2))
-        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 8 else "3")
+        monkeypatch.setenv("RTN_CONV_H8_MI", "4" if it < 4 else "3")
         gots, wants, ld, n = run_case(pkg, handle, "bf16", levels, 256, 256, 3, 1, "same", L.CONV_RELU, None, B=8, seed=5,
                                       reference=(it == 0))
         assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 4

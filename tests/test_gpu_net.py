@@ -398,3 +398,50 @@ def test_detect_parameters_and_shapes(pkg, K, B, hw, src, thr, nms, md):
     dcls = np.abs(cls - ecls.numpy()).max()
     print("K=%d B=%d %s %s: box %.3e px, score %.3e, %d detections" % (K, B, hw, src, dbox, dcls, n_det))
     assert dbox <= 2.0 and dcls <= 2e-2
+
+
+def test_batches_in_flight_give_the_bits_of_one_at_a_time(pkg):
+    """Engine.in_flight = 2: consecutive detect() calls run on two buffer sets, each on a HIP stream of its own, and overlap on the
+    device.  Five different batches through it (so both buffer sets are reused, the second time behind their own previous batch)
+    must give, after join(), exactly what the same batches give one at a time; the page tensor may be overwritten as soon as detect()
+    has returned (the packer consumed it in the caller's stream order)."""
+    E = importlib.import_module(pkg.__name__ + ".engine")
+    Wt = importlib.import_module(pkg.__name__ + ".weights")
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-3.0, tame=True)
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.load_state(state)
+    g = torch.Generator().manual_seed(9)
+    pages = [torch.randint(0, 256, (2, 160, 224, 3), generator=g, dtype=torch.uint8).cuda() for _ in range(5)]
+    want = []
+    for p in pages:
+        b, s, l = eng.detect(p)
+        torch.cuda.synchronize()
+        want.append((b.clone(), s.clone(), l.clone()))
+    assert sum(int((w[1] >= 0).sum()) for w in want) > 10              # there is something to compare
+    eng.in_flight = 2
+    buf = torch.empty_like(pages[0])
+    got = []
+    for p in pages:
+        buf.copy_(p)
+        got.append(eng.detect(buf))
+        buf.fill_(0)                                                   # the caller overwrites its page at once
+        if len(got) >= 2:                                              # the buffer set of call i is reused by call i + 2: copy i out first
+            eng.join()
+            got[-2] = tuple(t.clone() for t in got[-2])
+    eng.join()
+    got[-1] = tuple(t.clone() for t in got[-1])
+    torch.cuda.synchronize()
+    for i, (w, gt) in enumerate(zip(want, got)):
+        for a, b_ in zip(w, gt):
+            assert torch.equal(a, b_), "batch %d differs between one at a time and two in flight" % i
+    # ... and with nothing between the calls (the two batches really overlap): the last two results are still in their buffer sets
+    last = [eng.detect(p) for p in pages[1:5]][-2:]
+    eng.join()
+    torch.cuda.synchronize()
+    for w, gt in zip(want[3:5], last):
+        for a, b_ in zip(w, gt):
+            assert torch.equal(a, b_)
+    eng.in_flight = 1
+    b, s, l = eng.detect(pages[0])                                     # back to one at a time on the same engine
+    torch.cuda.synchronize()
+    assert torch.equal(b, want[0][0]) and torch.equal(s, want[0][1])

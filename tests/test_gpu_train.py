@@ -239,3 +239,42 @@ def test_per_tensor_clipnorm_switch(pkg):
     # Adam's first step has magnitude ~lr whatever the clip factor is, but elements with |g| near eps move differently: the two
     # semantics must not be the same code path
     assert any(float((moves[(True, n)] - moves[(False, n)]).abs().max()) > 0 for n in LAYERS)
+
+
+def test_plan_cache_is_bounded_over_many_canvases(pkg):
+    """csv_generator.compute_inputs pads every batch to its largest page, so fit_generator (RetinaNet.py:280, batch_size 1) sees a new
+    canvas for almost every page shape.  A forward plan (activations, descriptors, conv workspaces) and its backward plan (gradient
+    buffers, one row-info table + split slabs per weight gradient) are several GB at page size: the engine keeps the `max_plans`
+    most recently used canvases and the Trainer's backward plans go with them.  Twelve canvases through a cache of three: memory
+    stays flat after the third, a canvas that was evicted trains again and gives the bits it gave the first time (same weights)."""
+    E, Wt, T = mods(pkg)
+    L = pkg._lib
+    state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=-2.0, tame=True)
+    eng = E.Engine("resnet50", 1, 9, dtype="bf16")
+    eng.max_plans = 3
+    eng.load_state(state)
+    tr = T.Trainer(eng, lr=0.0, clipnorm=0.001)                        # lr 0: the weights stay, so a revisited canvas must repeat its bits
+    canvases = [(64 + 32 * (i % 4), 96 + 32 * (i // 4)) for i in range(12)]
+    g = torch.Generator().manual_seed(3)
+    first, mem = {}, []
+    for H, W in canvases + canvases[:2]:
+        x = (torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(H * 1000 + W)) * 2 - 1).cuda()
+        cfg, N = E.make_anchor_cfg((H, W))
+        reg_t = torch.zeros(1, N, 5, device="cuda")
+        lab_t = torch.zeros(1, N, 2, device="cuda")
+        lab_t[0, ::97, 0] = 1.0                                        # some positives: labels 1, anchor state 1
+        lab_t[0, ::97, 1] = 1.0
+        reg_t[0, ::97, 4] = 1.0
+        tr.forward_backward(x, reg_t, lab_t)
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        gsum = tr.grad.double().abs().sum().item()
+        assert np.isfinite(gsum) and gsum > 0
+        if (H, W) in first:
+            assert torch.equal(first[(H, W)], tr.grad.cpu()), "an evicted canvas came back with other gradients"
+        else:
+            first[(H, W)] = tr.grad.cpu().clone()
+        assert len(eng.plans) <= 3 and len(tr.bplans) <= 3
+        assert set(k[:3] for k in eng.plans) >= set(tr.bplans)         # no backward plan outlives its forward plan
+        mem.append(torch.cuda.memory_allocated())
+    assert max(mem[3:]) <= 1.35 * max(mem[:3]), "memory grew with the number of canvases seen: %s" % [m >> 20 for m in mem]
