@@ -153,6 +153,60 @@ def cpu_baseline(torch, state, threads):
             "sample": "%d x (1 image 800x1333: fp32 torch-CPU forward + NumPy decode/NMS), %.1f s" % (n, dt)}
 
 
+def train_algorithmic_bytes(eng, tr, bp, B, N, K, conv_bytes_fn):
+    """Algorithmic HBM bytes of one training step: every tensor an op must read once and write once - forward launches,
+    targets, loss forward / backward, every backward op (dY, X / filters, masks and residual gradients in; dX or dW out; the split
+    slabs of the weight gradients are NOT algorithmic), sum of squares, Adam (w, m, v, g in; w, m, v and the bf16 filters out) and
+    the data-gradient filter repack.  Returns (total, {group: bytes})."""
+    es = 2
+    plan = bp["plan"]
+    groups = {"forward": 0.0, "targets+loss": 0.0, "dgrad": 0.0, "wgrad": 0.0, "other backward": 0.0, "optimizer": 0.0}
+    eng.training = True
+    try:
+        ops = eng.active_ops(plan)
+    finally:
+        eng.training = False
+    for op in ops:
+        if op[0] in ("conv", "dual"):
+            groups["forward"] += conv_bytes_fn(op)
+        elif op[0] == "bneck":
+            m = op[3]
+            px = m["B"] * m["H"] * m["W"]
+            groups["forward"] += 2.0 * px * (64 + 256 + 256 + 64 + (64 if m.get("tail") else 0))
+        elif op[0] == "stem":
+            Bn, Hn, Wn = op[2]
+            groups["forward"] += Bn * (CANVAS[0] * CANVAS[1] * 4 * 2 + ((Hn + 1) // 2) * ((Wn + 1) // 2) * 64 * (2 + 2 + 1))
+    rows = B * N
+    groups["targets+loss"] = rows * (5 + 2) * 4 + 2 * rows * (2 + 5 + K + 4) * 4 + rows * (K + 4) * 4
+    for b in bp["bops"]:
+        kind = b[0]
+        if kind == "dgrad":
+            groups["dgrad"] += conv_bytes_fn(("conv", b[1]))
+        elif kind == "wgrad":
+            d = b[1]
+            t = d.N * d.KH * d.KW * d.Crun * 4
+            for i in range(d.ngroups):
+                g = d.g[i]
+                t += B * g.Hin * g.Win * d.pix_stride * es + B * g.Hout * g.Wout * d.out_ld * es
+            groups["wgrad"] += t
+        elif kind == "padcast":
+            groups["other backward"] += b[3] * (b[4] * 4 + b[5] * es)
+        elif kind == "zins":
+            Bn, Ho, Wo, Cc, Hs, Ws = b[3]
+            groups["other backward"] += Bn * Cc * es * (Ho * Wo + Hs * Ws)
+        elif kind == "upbwd":
+            Bn, Hd, Wd, Hs, Ws, Cc = b[3]
+            groups["other backward"] += Bn * Cc * es * (Hd * Wd + 2 * Hs * Ws)
+        elif kind == "poolbwd":
+            Bn, Hi, Wi, Cc = b[4]
+            groups["other backward"] += Bn * Cc * (((Hi + 1) // 2) * ((Wi + 1) // 2) * (es + 1 + es) + Hi * Wi * es)
+        elif kind == "bgrad":
+            groups["other backward"] += b[2] * b[4] * es
+    nparam = tr.NW + tr.NB
+    groups["optimizer"] = nparam * 4 * 2 + nparam * (4 * 4 + 3 * 4) + tr.NW * es + 2 * tr.NW * es
+    return sum(groups.values()), groups
+
+
 TRAIN_BATCH = 16                   # BASELINE.json configs[2]: batch 16 per GPU
 TRAIN_GFLOP_PER_IMAGE = 1248.4     # SURVEY.md §8(d): ~3x forward (dgrad + wgrad for every conv)
 
@@ -248,6 +302,15 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
     except Exception as e:              # the measurement beside the line may fail; the line itself may not
         dom = {"error": "%s: %s" % (type(e).__name__, e)}
     traffic, traffic_note = pmc_traffic_train()
+    alg_bytes, alg_groups = None, None
+    try:
+        bp = tr._bplan(B, CANVAS[0], CANVAS[1])
+
+        def cb(op):
+            return conv_bytes(op[1], B) + ((B * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
+        alg_bytes, alg_groups = train_algorithmic_bytes(eng, tr, bp, B, N, 1, cb)
+    except Exception as e:              # beside the line, like `dominant`
+        alg_groups = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"metric": "images/sec RetinaNet R50-FPN 800x1333 training step", "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -258,7 +321,11 @@ def measure_train(steps, warmup, torch, dist, E, Wt, rank, local_rank, world, de
             "roofline": {"bound": "mfma", "kernel": "conv fwd+dgrad+wgrad (whole step)", "achieved": achieved,
                          "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_DENSE_PEAK_TFLOPS,
                          "flop_per_step": TRAIN_GFLOP_PER_IMAGE * 1e9 * B, "traffic": traffic, "traffic_per": "step",
-                         "traffic_source": traffic_note, "dominant": dom}}
+                         "traffic_source": traffic_note,
+                         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_bytes_by_group": alg_groups,
+                         "hbm_floor_ms_at_6.3TBps": (alg_bytes / 6.3e12 * 1e3) if alg_bytes else None,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
+                         "dominant": dom}}
 
 
 def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):

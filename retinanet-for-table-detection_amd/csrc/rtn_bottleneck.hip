@@ -421,20 +421,20 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     { const int gl = rtn_env_int("RTN_BNECK_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: several strips per wave on small inputs
 #define RTN_BK_LAUNCH(T, NTH, RP)                                                                        \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, NTH, RP>,                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
     } while (0)
     const bool rowpp = rtn_bneck_rowpp(nt);
     if (proj) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {
             RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<false, 512, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));
-            attr_set = true;
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);
         }
         hipLaunchKernelGGL((bottleneck64_kernel<false, 512, true, true>), dim3((unsigned)grid), dim3(512), BK_LDS, h->stream, p);
     } else if (nt == 768) {

@@ -1672,11 +1672,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         p.korder_kw = d->KW;
 #define RTN_L3(E, B)                                                                                     \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm3_kernel<E, B>,                        \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_igemm3_kernel<E, B>), gdim, bdim, ldsb, h->stream, p);                  \
     } while (0)
@@ -1709,11 +1709,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
         if (ldsb < epib) ldsb = epib;
 #define RTN_L2K(E, B, I)                                                                                 \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm2_kernel<E, B, I>,                     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_igemm2_kernel<E, B, I>), gdim, bdim, ldsb, h->stream, p);               \
     } while (0)
@@ -1723,11 +1723,11 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     } while (0)
 #define RTN_L2D(E, B)                                                                                    \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_igemm2_kernel<E, B, false, true>,           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_igemm2_kernel<E, B, false, true>), gdim, bdim, ldsb, h->stream, p);     \
     } while (0)

@@ -758,11 +758,11 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     }
 #define RTN_G8_LAUNCH_SK(M_, DU, EP)                                                                     \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, true, DU, EP, 8, true>,    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_gemm8_kernel<M_, true, DU, EP, 8, true>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
     } while (0)
@@ -774,11 +774,11 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     } while (0)
 #define RTN_G8_LAUNCH(M_, ST, DU, EP)                                                                    \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, ST, DU, EP>,               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_gemm8_kernel<M_, ST, DU, EP>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
     } while (0)
@@ -793,11 +793,11 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     } while (0)
 #define RTN_G8_LAUNCH4(M_, EP)                                                                           \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_gemm8_kernel<M_, true, false, EP, 4>,       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_gemm8_kernel<M_, true, false, EP, 4>), dim3((unsigned)grid), dim3(G8_THREADS), G8_LDS, h->stream, p); \
     } while (0)

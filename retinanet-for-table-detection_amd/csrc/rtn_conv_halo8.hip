@@ -874,21 +874,21 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (grid > p.nitems) grid = p.nitems;
 #define RTN_H8_LAUNCH(M_, ST, EP, SP)                                                                    \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, ST, EP, SP>,            \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, ST, EP, SP>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
 #define RTN_H8_LAUNCH4E(M_, EP)                                                                          \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, EP, false, 4>,    \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, EP, false, 4>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)
@@ -899,11 +899,11 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     } while (0)
 #define RTN_H8_LAUNCH8F(M_)                                                                              \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halo8_kernel<3, M_, true, 0, false, 8, 1>,  \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, H8_LDS));         \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_halo8_kernel<3, M_, true, 0, false, 8, 1>), dim3((unsigned)grid), dim3(H8_THREADS), H8_LDS, h->stream, p); \
     } while (0)

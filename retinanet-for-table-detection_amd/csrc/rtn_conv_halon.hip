@@ -388,11 +388,11 @@ int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     if (grid > p.ntiles) grid = p.ntiles;
 #define RTN_HN_LAUNCH(NF_)                                                                               \
     do {                                                                                                 \
-        static bool attr_set = false;                                                                    \
-        if (!attr_set) {                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_halon_kernel<NF_>,                          \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, HNCfg<NF_>::LDS)); \
-            attr_set = true;                                                                             \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
         }                                                                                                \
         hipLaunchKernelGGL((conv_halon_kernel<NF_>), dim3((unsigned)grid), dim3(HN_THREADS), HNCfg<NF_>::LDS, h->stream, p); \
     } while (0)

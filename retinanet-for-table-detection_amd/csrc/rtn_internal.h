@@ -1,6 +1,7 @@
 // rtn_internal.h — shared by the librtn.so translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>

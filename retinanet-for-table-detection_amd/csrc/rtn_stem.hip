@@ -317,10 +317,10 @@ static int stem_launch(rtn_handle_t h, const void* packed, int Hp, int Wp, const
     if (grid > ntiles) grid = ntiles;
 #define RTN_STEM_LAUNCH(A2_, IDX_, LDSB)                                                                       \
     do {                                                                                                      \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) {                                                                                      \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                         \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                      \
             RTN_HIP(h, hipFuncSetAttribute((const void*)stem_fused_kernel<A2_, IDX_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
-            attr_set = true;                                                                                  \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                                  \
         }                                                                                                     \
         hipLaunchKernelGGL((stem_fused_kernel<A2_, IDX_>), dim3((unsigned)grid), dim3(256), LDSB, h->stream, p); \
     } while (0)

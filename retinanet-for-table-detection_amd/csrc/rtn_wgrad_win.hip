@@ -453,19 +453,19 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
     const unsigned grid = (unsigned)(p.ntiles * ((S + 7) / 8) * 8);
 #define RTN_WW_LAUNCH(E_, PS_)                                                                                                    \
     do {                                                                                                                          \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                                             \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                                          \
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<E_, PS_>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX)); \
-            attr_set = true;                                                                                                      \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                                                      \
         }                                                                                                                         \
         hipLaunchKernelGGL((conv_wgrad_win_kernel<E_, PS_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);              \
     } while (0)
     const int dbg = rtn_env_int("RTN_WGRAD_WIN_DBG", 0);    // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
     if (!ps && rtn_env_int("RTN_WGRAD_WIN_STAGGER", 1) == 0) {       // A/B: every wave stages right behind the barrier
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {
             RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX));
-            attr_set = true;
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);
         }
         hipLaunchKernelGGL((conv_wgrad_win_kernel<0, false, false>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);
     } else if (ps) {

@@ -698,8 +698,8 @@ class Engine:
             return plan["regression"], plan["classification"]
         sched = plan["variants"][fused][1] if fused else plan["sched"]
         main = torch.cuda.current_stream(self.device)
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        if self._side is None:                               # three lanes that do not share a hardware queue with each other or with `main`
+            self._side = self._concurrent_streams(3, beside=(main,))
         streams = [main] + self._side
         lanes, waits = sched["lanes"], sched["waits"]
         events = plan.setdefault(("events", fused), {i: torch.cuda.Event() for i in sched["events"]})
@@ -898,15 +898,15 @@ class Engine:
         self.h.set_stream(caller.cuda_stream)
         return boxes, scores, labels
 
-    def _concurrent_streams(self, n):
-        """n HIP streams whose kernels really run beside each other.  The runtime multiplexes HIP streams onto a few hardware queues
+    def _concurrent_streams(self, n, beside=()):
+        """n HIP streams whose kernels really run beside each other (and beside the streams in `beside`).  The runtime multiplexes HIP streams onto a few hardware queues
         (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one are served strictly in turn: batches "in flight" on such a
         pair do not overlap at all (measured: 4.28 against 3.60 ms per batch, and WHICH streams of torch's pool collide changes with
         the streams created before; profiles/r4_in_flight.txt).  So candidates are tested, once: a one-workgroup spin kernel
         (torch.cuda._sleep) on the candidate and on every stream already chosen must take the time of one, not of two."""
         sleep = getattr(torch.cuda, "_sleep", None)
         chosen = []
-        if sleep is None:
+        if sleep is None or os.environ.get("RTN_STREAM_SELECT", "1") == "0":
             return [torch.cuda.Stream(device=self.device) for _ in range(n)]
         import time
         cycles = 400000
@@ -926,7 +926,7 @@ class Engine:
             cand = torch.cuda.Stream(device=self.device)
             spin([cand])                                             # first use of a stream: not timed
             one = min(spin([cand]) for _ in range(2))
-            if all(min(spin([cand, c]) for _ in range(2)) < 1.5 * one for c in chosen):
+            if all(min(spin([cand, c]) for _ in range(2)) < 1.5 * one for c in list(beside) + chosen):
                 chosen.append(cand)
         while len(chosen) < n:                                       # (no overlapping set found: the batches still run, one queue at a time)
             chosen.append(torch.cuda.Stream(device=self.device))

@@ -32,10 +32,13 @@ class GradBucketer:
     latest event of a stream covers every earlier layer on it.  When a bucket is complete its all-reduce is issued on the
     communication stream behind ALL of the bucket's events.  finish() issues what is left and makes the compute stream wait."""
 
-    def __init__(self, flat, segments, group=None, bucket_bytes=32 << 20):
+    def __init__(self, flat, segments, group=None, bucket_bytes=32 << 20, stream_layer=None):
+        """stream_layer: an object with torch.cuda's current_stream / Stream / Event / stream (tests pass a recording stub and drive the
+        event logic on the CPU); None = torch.cuda when `flat` lives on a GPU, no streams at all otherwise."""
         self.flat, self.group = flat, group
-        self.cuda = flat.is_cuda
-        self.comm = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.tc = stream_layer if stream_layer is not None else torch.cuda
+        self.cuda = flat.is_cuda or stream_layer is not None
+        self.comm = self.tc.Stream(device=flat.device) if self.cuda else None
         es = flat.element_size()
         self.buckets, cur, size = [], [], 0
         for seg in reversed(segments):
@@ -54,6 +57,7 @@ class GradBucketer:
         self.pending = [set(seg[0] for seg in b) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.work = []
+        self.last_marks = [set(m) for m in getattr(self, "marks", [])]     # streams each bucket of the step before waited for (tests)
         self.marks = [{} for _ in self.buckets]          # bucket -> {stream id: (stream, event recorded after its last layer there)}
 
     def _launch(self, bi):
@@ -65,7 +69,7 @@ class GradBucketer:
             marks = self.marks[bi]
             if not marks:                                 # finish() on a bucket no layer reported: order behind the caller's stream
                 self._mark(bi)
-            with torch.cuda.stream(self.comm):
+            with self.tc.stream(self.comm):
                 for _, ev in marks.values():
                     self.comm.wait_event(ev)
                 self.work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -73,8 +77,8 @@ class GradBucketer:
             self.work.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _mark(self, bi):
-        st = torch.cuda.current_stream(self.flat.device)
-        pool = self._events.setdefault((bi, st.cuda_stream), torch.cuda.Event())
+        st = self.tc.current_stream(self.flat.device)
+        pool = self._events.setdefault((bi, st.cuda_stream), self.tc.Event())
         pool.record(st)
         self.marks[bi][st.cuda_stream] = (st, pool)
 
@@ -102,5 +106,5 @@ class GradBucketer:
         for w in self.work:
             w.wait()
         if self.cuda:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+            self.tc.current_stream(self.flat.device).wait_stream(self.comm)
         self.reset()

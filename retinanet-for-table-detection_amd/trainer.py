@@ -489,7 +489,8 @@ class Trainer:
                 bp[key] = sch
             sch = bp[key]
             if self._wg_stream is None or len(self._wg_stream) < sch["nlanes"] - 1:
-                self._wg_stream = [torch.cuda.Stream(device=eng.device) for _ in range(self.WG_LANES + 2)]
+                # lanes on hardware queues of their own as far as the runtime has them (Engine._concurrent_streams)
+                self._wg_stream = eng._concurrent_streams(self.WG_LANES + 2, beside=(main,))
                 self._wg_ev = torch.cuda.Event()
             streams = [main] + self._wg_stream[:sch["nlanes"] - 1]
             self._wg_ev.record(main)                      # side lanes start behind the loss backward and the gradient reset

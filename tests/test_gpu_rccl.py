@@ -67,6 +67,26 @@ def _worker(rank, port, outdir):
         if pg is not None:
             assert tr.bucketer is not None and len(tr.bucketer.buckets) >= 2
             assert tr.wgrad_lanes == 3                         # the lanes stay on under data parallelism
+            # With one rank the all-reduce is the identity, so a missing event wait could not change a bit: check the waits themselves.
+            # Every bucket's all-reduce must have been issued behind an event on EVERY stream that produced one of its layers'
+            # weight gradients (GradBucketer.last_marks = the streams each bucket waited for in the last step), and the bias
+            # bucket - fed by fused bias gradients on every weight-gradient lane - behind all of those lanes.
+            bp = tr._bplan(B, CANVAS[0], CANVAS[1])
+            sch = bp[("bsched", tr.wgrad_lanes)]
+            main = torch.cuda.current_stream(device)
+            streams = [main] + tr._wg_stream[:sch["nlanes"] - 1]
+            need = [set() for _ in tr.bucketer.buckets]
+            wg_lanes = set()
+            for bi_, b_ in enumerate(bp["bops"]):
+                if b_[0] == "wgrad":
+                    sid = streams[sch["lanes"][bi_]].cuda_stream
+                    wg_lanes.add(sid)
+                    if b_[3] in tr.bucketer.where:
+                        need[tr.bucketer.where[b_[3]]].add(sid)
+            need[tr.bucketer.where["__biases__"]] |= {sid for sid in wg_lanes if sid != main.cuda_stream}
+            assert len(wg_lanes) >= 3
+            for bi_, want_ in enumerate(need):
+                assert want_ <= tr.bucketer.last_marks[bi_], "bucket %d went out without waiting for streams %s" % (bi_, want_ - tr.bucketer.last_marks[bi_])
             t = torch.ones(4, device=device)
             dist.all_reduce(t)
             dist.barrier()

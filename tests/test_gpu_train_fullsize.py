@@ -59,7 +59,7 @@ def make_batch(B, seed):
         gts.append(np.stack([x1, y1, x1 + w, y1 + h], axis=1).reshape(n, 4))
         shapes.append((CANVAS[0], int(rng.randint(1100, CANVAS[1] + 1))))
     reg, lab = R.anchor_targets(anchors, shapes, gts, [np.zeros(len(g_)) for g_ in gts], 1)
-    assert reg.shape == (B, 200700, 5) and (lab[..., 1] == 1).sum() > 50
+    assert reg.shape == (B, 200700, 5) and (lab[..., 1] == 1).sum() > (50 if B > 1 else 5)
     return x, reg, lab
 
 

@@ -39,10 +39,13 @@ for rnd in range(10):
         for k in KNOBS: os.environ.pop(k, None)
         os.environ.update(v)
         wsb = L.lib.rtn_conv2d_wgrad_workspace_bytes(C.byref(d)); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-        h.check(L.lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb)); torch.cuda.synchronize()
+        # as the training step does: the row-info table once (rtn_conv2d_wgrad_rowinfo), then prepared launches - the general kernels' A/B
+        # baseline must not carry a 16 B-per-pixel table write that the window kernel's does not (round-3 advisor note)
+        h.check(L.lib.rtn_conv2d_wgrad_rowinfo(h.raw, C.byref(d), ws.data_ptr(), wsb))
+        h.check(L.lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb)); torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(5): h.check(L.lib.rtn_conv2d_wgrad_bias(h.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
+        for _ in range(5): h.check(L.lib.rtn_conv2d_wgrad_prepared(h.raw, C.byref(d), dW.data_ptr(), db.data_ptr(), cout, ws.data_ptr(), wsb))
         e.record(); torch.cuda.synchronize()
         if rnd >= 2: times[i].append(s.elapsed_time(e) / 5)
 for i, v in enumerate(variants):
