@@ -150,6 +150,9 @@ int rtn_conv_workspace_init(rtn_handle_t h, void* workspace, size_t workspace_by
  * launch), 0 otherwise.  rtn_debug_conv_sync_timeouts: synchronises the stream and reads the sync block's error word - the number of
  * bounded flag polls that gave up (always 0 unless a workgroup of a launch never ran). */
 int rtn_debug_last_conv_streamk(rtn_handle_t h);
+/* (tile rows << 16) | tile columns of the last convolution launch on this handle (the persistent kernels: 128 / 192 / 256 staged rows
+ * x 128 / 256 columns; generations 1-3: 128 or 256 x 64 / 128 / 256).  For the launch-plan table of DESIGN.md (tools/launch_plan.py). */
+int rtn_debug_last_conv_tile(rtn_handle_t h);
 int rtn_debug_conv_sync_timeouts(rtn_handle_t h, const void* workspace, unsigned* count);
 /* Which kernel generation the last convolution launch on this handle ran (1: 128-row register-staged, 2: 256-row LDS-DMA per tap,
  * 3: 256-row shared halo, 4: persistent 8-phase halo kernel, 5: persistent 1x1 kernel, 6: narrow-N head-output kernel).  For tests and profiles: proves which native path executed. */

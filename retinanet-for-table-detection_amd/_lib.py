@@ -105,6 +105,7 @@ SIGNATURES = {
     "rtn_conv1x1_dual_workspace_bytes": (_SZ, [_P, C.POINTER(ConvDesc), C.POINTER(ConvSrc2)]),
     "rtn_conv_workspace_init": (_I, [_P, _P, _SZ]),
     "rtn_debug_last_conv_streamk": (_I, [_P]),
+    "rtn_debug_last_conv_tile": (_I, [_P]),
     "rtn_debug_conv_sync_timeouts": (_I, [_P, _P, C.POINTER(C.c_uint32)]),
     "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),

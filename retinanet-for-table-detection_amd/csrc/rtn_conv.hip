@@ -1384,7 +1384,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     unsigned* const ws_sync = ws_ok ? (unsigned*)d->workspace : nullptr;
     float* const ws_ptr = ws_ok ? (float*)((char*)d->workspace + RTN_CONV_SYNC_BYTES) : nullptr;
     const long long ws_cap = query ? kMaxConvWorkspace : (ws_ptr ? (long long)d->workspace_bytes - RTN_CONV_SYNC_BYTES : 0);
-    if (!query) h->last_conv_streamk = 0;
+    if (!query) { h->last_conv_streamk = 0; h->last_conv_tile = 0; }
 
     KParams p;
     memset(&p, 0, sizeof(p));
@@ -1789,6 +1789,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     }
     RTN_CHECK_LAUNCH(h, "conv_igemm_kernel");
     h->last_conv_impl = impl;
+    h->last_conv_tile = ((impl >= 2 ? BM2 : BM) << 16) | BN;
     return RTN_OK;
 }
 
@@ -1818,6 +1819,7 @@ extern "C" int rtn_conv_workspace_init(rtn_handle_t h, void* workspace, size_t w
     return RTN_OK;
 }
 extern "C" int rtn_debug_last_conv_streamk(rtn_handle_t h) { return h ? h->last_conv_streamk : RTN_EINVAL; }
+extern "C" int rtn_debug_last_conv_tile(rtn_handle_t h) { return h ? h->last_conv_tile : RTN_EINVAL; }
 extern "C" int rtn_debug_conv_sync_timeouts(rtn_handle_t h, const void* workspace, unsigned* count) {
     if (!h) return RTN_EINVAL;
     if (!workspace || !count) return rtn_fail(h, RTN_EINVAL, "conv sync timeouts: null argument");

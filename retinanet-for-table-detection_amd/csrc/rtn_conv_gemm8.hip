@@ -818,6 +818,7 @@ int rtn_conv_gemm8_try(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
 #undef RTN_G8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_gemm8_kernel");
     h->last_conv_streamk = sk_grid;
+    h->last_conv_tile = ((64 * mi) << 16) | (narrow ? 128 : 256);
     return RTN_OK;
 }
 

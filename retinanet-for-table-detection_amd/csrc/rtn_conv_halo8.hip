@@ -925,6 +925,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
 #undef RTN_H8_LAUNCH4E
 #undef RTN_H8_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_halo8_kernel");
+    h->last_conv_tile = ((64 * mi) << 16) | (half ? 128 : 256);
     if (S > 1) return rtn_conv_ksplit_finish(h, ws, S, Mtot, d->N, (int)slab_ld, d->bias, p.relu, d->g[0].out, d->out_ld);
     return RTN_OK;
 }

@@ -13,6 +13,7 @@ struct rtn_ctx {
     void* zero_page;        // 256 B of zeros on the device: source for out-of-image taps
     int num_cus;
     int last_conv_streamk;        // rtn_debug_last_conv_streamk: workgroups of the last conv launch if it ran in stream-K form, else 0
+    int last_conv_tile;           // rtn_debug_last_conv_tile: (tile rows << 16) | tile columns of the last conv launch
     int last_conv_impl;
          // kernel generation of the last conv launch on this handle (rtn_debug_last_conv_impl)
     int last_wgrad_impl;          // rtn_debug_last_wgrad_impl: 2 = 256x256 LDS-DMA, 3 = 128x128 LDS-DMA, 4 = rtn_wgrad_win.hip, 0 = register-staged
