@@ -364,6 +364,71 @@ def test_gemm8_stream_k(pkg, handle, monkeypatch, levels, cin, cout, stride, res
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("H,W,c1,c2,cout,step,B,grid", [
+    (13, 21, 512, 1024, 2048, 2, 4, 0),        # res5a_branch2c + branch1: 24 K steps over two sources, 8 column blocks, the cost model's grid
+    (25, 42, 256, 512, 1024, 2, 2, 5),         # res4a-like on 5 workgroups: ranges cross tiles AND the seam between the two sources
+    (17, 23, 64, 64, 256, 1, 3, 3),            # one K step per source
+])
+def test_dual_source_stream_k(pkg, handle, monkeypatch, H, W, c1, c2, cout, step, B, grid):
+    """rtn_conv1x1_dual_fwd (a stage's first block: branch2c with the projection shortcut appended along K, model/defineModel.py:376-380)
+    in stream-K form: its workspace comes from rtn_conv1x1_dual_workspace_bytes.  Small-integer operands: bit-identical to the unsplit
+    launch and to the float64 sum of the two products; random operands: same bits on every launch, within one bf16 ulp of the unsplit one."""
+    L = pkg._lib
+    dev = torch.device("cuda")
+    monkeypatch.setenv("RTN_CONV_IMPL", "5")
+    monkeypatch.setenv("RTN_CONV_H8_GRID", str(grid))
+    g = torch.Generator().manual_seed(77 + grid)
+    Hs, Ws = (H - 1) * step + 1, (W - 1) * step + 1
+
+    def run(exact, sk):
+        monkeypatch.setenv("RTN_CONV_G8_SK", sk)
+        gg = torch.Generator().manual_seed(1000 + grid + (1 if exact else 0))
+        if exact:
+            a = torch.randint(-3, 4, (B, H, W, c1), generator=gg).double(); x2 = torch.randint(-3, 4, (B, Hs, Ws, c2), generator=gg).double()
+            w = torch.randint(-2, 3, (cout, c1 + c2), generator=gg).double(); bias = torch.randint(-8, 9, (cout,), generator=gg).double()
+        else:
+            a = torch.randn(B, H, W, c1, generator=gg, dtype=torch.float64); x2 = torch.randn(B, Hs, Ws, c2, generator=gg, dtype=torch.float64)
+            w = torch.randn(cout, c1 + c2, generator=gg, dtype=torch.float64) / math.sqrt(c1 + c2); bias = torch.randn(cout, generator=gg, dtype=torch.float64)
+        aq, xq, wq = q(a, "bf16"), q(x2, "bf16"), q(w, "bf16")
+        want = torch.relu(torch.einsum("bhwc,nc->bhwn", aq, wq[:, :c1]) + torch.einsum("bhwc,nc->bhwn", xq[:, ::step, ::step], wq[:, c1:]) + bias.float().double())
+        ad, xd = a.to(torch.bfloat16).to(dev).contiguous(), x2.to(torch.bfloat16).to(dev).contiguous()
+        wd, bd = w.to(torch.bfloat16).to(dev).contiguous(), bias.float().to(dev)
+        out = torch.full((B, H, W, cout), -77.0, dtype=torch.bfloat16, device=dev)
+        d = L.ConvDesc()
+        d.ngroups, d.batch, d.dtype = 1, B, L.RTN_BF16
+        d.w, d.bias, d.w_rows, d.N, d.KH, d.KW = wd.data_ptr(), bd.data_ptr(), cout, cout, 1, 1
+        d.Crun = d.pix_stride = c1
+        d.sy = d.sx = 1
+        d.out_ld, d.flags = cout, L.CONV_RELU
+        grp = d.g[0]
+        grp.in_, grp.in_elems, grp.in_img_stride, grp.in_row_stride = ad.data_ptr(), ad.numel(), H * W * c1, W * c1
+        grp.Hin, grp.Win, grp.Hout, grp.Wout = H, W, H, W
+        grp.out, grp.out_elems, grp.out_img_stride = out.data_ptr(), out.numel(), H * W * cout
+        s2 = L.ConvSrc2()
+        s2.in_, s2.in_elems, s2.in_img_stride, s2.in_row_stride, s2.pix_stride = xd.data_ptr(), xd.numel(), Hs * Ws * c2, Ws * c2, c2
+        s2.Hin, s2.Win, s2.C, s2.step = Hs, Ws, c2, step
+        L.attach_conv_workspace(handle, d, s2)
+        handle.check(L.lib.rtn_conv1x1_dual_fwd(handle.raw, C.byref(d), C.byref(s2)))
+        torch.cuda.synchronize()
+        assert L.lib.rtn_debug_last_conv_impl(handle.raw) == 5
+        assert (L.lib.rtn_debug_last_conv_streamk(handle.raw) > 0) == (sk == "1")
+        if sk == "1":
+            n = C.c_uint32(9)
+            handle.check(L.lib.rtn_debug_conv_sync_timeouts(handle.raw, d.workspace, C.byref(n)))
+            assert n.value == 0
+        return out.cpu().double(), want
+
+    e1, want = run(True, "1")
+    e0, _ = run(True, "0")
+    assert torch.equal(e1, e0) and torch.equal(e1, q(want, "bf16"))
+    r1, want = run(False, "1")
+    r0, _ = run(False, "0")
+    scale = max(1.0, float(want.abs().max()))
+    assert float((r1 - want).abs().max()) <= 1e-2 * scale and float((r1 - r0).abs().max()) <= 8e-3 * scale
+    r1b, _ = run(False, "1")
+    assert torch.equal(r1, r1b)
+
+
 @pytest.mark.parametrize("levels,cin,cout,B,grid,mi,ksplit", [
     ([(25, 42)], 512, 512, 2, 0, 0, 0),       # res5 branch2b: two column blocks; tile height and K slices by the cost model
     ([(25, 42)], 512, 512, 2, 3, 4, 1),       # ... unsliced: the epilogue adds the bias (accumulators of a block item start at zero)
