@@ -13,6 +13,7 @@ echo "== kernel trace / stats (inference, the bench default: two batches in flig
 echo "== kernel trace / stats (inference, one batch at a time, lanes on)"; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/kt.log 2>&1
 echo "== kernel trace / stats (inference, one stream)"; RTN_TWO_STREAMS=0 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/kt1.log 2>&1
 echo "== kernel trace / stats (training)"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt -- python3 bench.py --mode train --steps 5 --warmup 2 > $O/ktt.log 2>&1
+echo "== kernel trace / stats (training, every launch alone on the device: no lanes)"; RTN_WGRAD_LANE=0 RTN_TWO_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktt1 -- python3 bench.py --mode train --steps 5 --warmup 2 > $O/ktt1.log 2>&1
 for P in "f:FETCH_SIZE" "w:WRITE_SIZE" "m:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "s:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   k=${P%%:*}; c=${P#*:}
   echo "== pmc $c (inference)"; timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$k -- $B > $O/pmc_$k.log 2>&1
@@ -27,10 +28,11 @@ cp "$(statof kt2)" $O/bench_kernel_stats_two_in_flight.csv 2>/dev/null
 cp "$(statof kt)" $O/bench_kernel_stats.csv 2>/dev/null
 cp "$(statof kt1)" $O/bench_kernel_stats_one_stream.csv 2>/dev/null
 cp "$(statof ktt)" $O/train_kernel_stats.csv 2>/dev/null
+cp "$(statof ktt1)" $O/train_kernel_stats_one_stream.csv 2>/dev/null
 RTN_GIT_COMMIT=$COMMIT python3 tools/pmc_traffic.py "$(csvof pmc_f)" "$(csvof pmc_w)" 7.125 $O/pmc_traffic.json $O/pmc_f.log > $O/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma_util.py "$(csvof pmc_m)" "$(csvof pmc_s)" $O/pmc_mfma_util.json > $O/pmc_mfma_util.txt 2>&1
 python3 tools/pmc_train.py "$(csvof pmct_f)" "$(csvof pmct_w)" "$(csvof pmct_m)" 4 16 $COMMIT $O/pmc_train_traffic.json $O/pmc_train_mfma_util.json > $O/pmc_train.txt 2>&1
 echo "== layer times"; timeout -k 10 200 python3 tools/profile_layers.py > $O/layer_times.txt 2>&1
 echo "== train breakdown"; timeout -k 10 300 python3 tools/profile_train.py 8 > $O/train_step_breakdown.txt 2>&1
-rm -rf $O/kt2 $O/kt $O/kt1 $O/ktt $O/pmc_f $O/pmc_w $O/pmc_m $O/pmc_s $O/pmct_f $O/pmct_w $O/pmct_m
+rm -rf $O/kt2 $O/kt $O/kt1 $O/ktt $O/ktt1 $O/pmc_f $O/pmc_w $O/pmc_m $O/pmc_s $O/pmct_f $O/pmct_w $O/pmct_m
 ls -la $O; tail -3 $O/pmc_traffic.txt; tail -5 $O/pmc_train.txt; head -4 $O/train_step_breakdown.txt

@@ -1,6 +1,8 @@
 """The HBM-bound kernels of the path against the achievable HBM rate (6.3 TB/s): algorithmic bytes per launch (every tensor
 read once, written once) / average launch duration from `rocprofv3 --kernel-trace --stats` of the bench commands.
-  python tools/hbm_table.py <train_kernel_stats.csv> <bench_kernel_stats_one_stream.csv>"""
+  python tools/hbm_table.py <train_kernel_stats_one_stream.csv> <bench_kernel_stats_one_stream.csv>
+Both traces must be the ONE-STREAM ones (RTN_WGRAD_LANE=0 RTN_TWO_STREAMS=0 / --in-flight 1): with lanes a short kernel's recorded duration
+includes the time it shares the device with its neighbours (the finish passes read 5-8 us alone and 100 us beside a weight gradient)."""
 import csv, ctypes as C, importlib, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch, bench
@@ -15,7 +17,10 @@ def stats(path):
             name = re.sub(r"\(anonymous namespace\)::", "", r["Name"]).replace("void ", "")
             name = re.sub(r"\(.*", "", name)
             c, t = out.get(name, (0, 0.0))
-            out[name] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
+            calls, total = int(r["Calls"]), float(r["TotalDurationNs"])
+            if name.startswith("pack_dgrad") and calls > 1:      # without the process's first dispatch (profiles/r4_first_repack.txt)
+                total = (total - float(r["MaxNs"])) * calls / (calls - 1)
+            out[name] = (c + calls, t + total)
     return out
 
 
@@ -69,8 +74,6 @@ for name, where, by in entries:
         c, t = st.get(name, (0, 0.0))
     if not c:
         print("%-42s %-6s (not in this trace)" % (name, where)); continue
-    if name.startswith("pack_dgrad"):                    # drop the first dispatch of the process (exp_first_repack.py)
-        pass
     us = t / steps / 1e3
     if by is None:
         print("%-42s %-6s %14s %10.1f %10s %8s   (%.1f launches / step; candidates only: latency-bound)" % (name, where, "-", us, "-", "-", c / steps))
