@@ -1150,7 +1150,7 @@ static WgradPlan wgrad_plan(const rtn_conv_desc_t* d, int cus) {
     if (nsplit > w.tiles) nsplit = w.tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;
-    w.xcd_map = nsplit >= 8 && rtn_env_int("RTN_WGRAD_XCD", -1) == -1;        // any value: off
+    w.xcd_map = nsplit >= 8;
     if (w.xcd_map) nsplit &= ~7ll;
     w.tiles_per_split = (int)((w.tiles + nsplit - 1) / nsplit);
     w.nsplit_used = (w.tiles + w.tiles_per_split - 1) / w.tiles_per_split;      // splits that own at least one pixel tile

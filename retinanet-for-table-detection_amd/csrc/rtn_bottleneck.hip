@@ -412,7 +412,7 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     p.nstrips = (int)((M + 31) / 32);
     p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
     p.inv_w = 1.0f / (float)d->W;
-    p.dbg = rtn_env_int("RTN_BNECK_DBG", 0);
+    p.dbg = 0;                                         // (timing ablations of round 2: profiles/r2_v2_bottleneck_fused.txt)
     // 12 waves per CU (154 VGPRs: three per SIMD) keep 1.5 x the loads of 8 in flight; RTN_BNECK_THREADS=512 for the A/B
     const int nt = rtn_bneck_threads();
     int grid = h->num_cus > 0 ? h->num_cus : 256;

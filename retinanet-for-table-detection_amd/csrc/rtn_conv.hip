@@ -1278,8 +1278,7 @@ __global__ __launch_bounds__(NT2, 2) void conv_igemm3_kernel(const KParams p) {
 }
 
 // Tuning knobs, read on every call so one process can A/B them: RTN_CONV_IMPL=1|2 forces a kernel generation
-// (unset/0 = heuristic); RTN_CONV_IL=1 interleaves the staging DMA issues between MFMA groups
-// instead of issuing them ahead of the MFMA block (measured slower: 1084 vs 1226 TF/s on the head layers).
+// (unset/0 = heuristic).
 int rtn_conv_impl_override() {
     const int v = rtn_env_int("RTN_CONV_IMPL", 0);
     return (v >= 1 && v <= 6) ? v : 0;                 // 4 / 5 / 6 = the persistent kernels (rtn_conv_halo8.hip / rtn_conv_gemm8.hip / rtn_conv_halon.hip) where they apply
@@ -1661,10 +1660,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     if (impl == 3) {
         dim3 bdim(NT2);
         const unsigned epib = 8u * 32u * (unsigned)(BN / 2 + 4) * 4u;
-        int nbst = 2;      // RTN_CONV_STAGES=3: a third B stage (fits beside the halos for every tile width) changed nothing measurable
-        const int nbst_env = rtn_env_int("RTN_CONV_STAGES", 0);
-        if (nbst_env == 2 || nbst_env == 3) nbst = nbst_env;
-        if (d->KW < 3) nbst = 2;
+        const int nbst = 2;      // (a third B stage fits beside the halos for every tile width and changed nothing measurable: round 1)
         p.nstages = nbst;
         unsigned ldsb = 2u * BM2 * 128u + (unsigned)nbst * (unsigned)BN * 128u;
         if (ldsb < epib) ldsb = epib;
@@ -1686,21 +1682,18 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
 #undef RTN_L3
     } else if (impl == 2) {
         dim3 bdim(NT2);
-        const bool il = rtn_env_int("RTN_CONV_IL", 0) != 0;
         // LDS: one stage when the K loop is a single step (the streaming 1x1 layers: more workgroups per CU), else two
         // LDS ring depth: as many stages as fit 160 KB (64-wide: 3 by default, 128-wide: 3, 256-wide: 2), never more
-        // than the K loop has steps.  RTN_CONV_STAGES=1..4 overrides (A/B knob).
+        // than the K loop has steps.
         const unsigned epib = 8u * 32u * (unsigned)(BN / 2 + 4) * 4u;     // the wave-private epilogue slices (EPI_BYTES)
         const unsigned sb = (unsigned)(BM2 + BN) * 128u;
         int nst = 2;   // measured: deeper rings lose (they cost the second resident workgroup on the 64-wide tile)
-        const int nst_env = rtn_env_int("RTN_CONV_STAGES", 0);
-        if (nst_env >= 1 && nst_env <= 4) nst = nst_env;
         while (nst > 1 && (unsigned)nst * sb > 160u * 1024u) --nst;
         if (nst > p.nkt) nst = p.nkt;
         if (nst < 2 && p.nkt > 1) nst = 2;
-        // K-step order: (chunk, kw) inside a kernel row when a tap spans whole 128-byte chunks (RTN_CONV_KORDER=0: in order)
+        // K-step order: (chunk, kw) inside a kernel row when a tap spans whole 128-byte chunks
         p.korder_chunks = p.nkt; p.korder_kw = 1;
-        if (d->KW > 1 && (d->Crun * es) % 128 == 0 && rtn_env_int("RTN_CONV_KORDER", 1) != 0) {
+        if (d->KW > 1 && (d->Crun * es) % 128 == 0) {
             p.korder_chunks = d->Crun * es / 128;
             p.korder_kw = d->KW;
         }
@@ -1719,7 +1712,7 @@ static int conv_launch(rtn_handle_t h, const rtn_conv_desc_t* d, const rtn_conv_
     } while (0)
 #define RTN_L2(E, B)                                                                                     \
     do {                                                                                                 \
-        if (il) RTN_L2K(E, B, true); else RTN_L2K(E, B, false);                                          \
+        RTN_L2K(E, B, false);   /* (DMA issues interleaved with the MFMA groups: measured 12 % slower in round 1, instance removed) */ \
     } while (0)
 #define RTN_L2D(E, B)                                                                                    \
     do {                                                                                                 \

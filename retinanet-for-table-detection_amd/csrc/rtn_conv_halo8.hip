@@ -864,8 +864,8 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.mask_ld = (epi & 2) ? d->g[0].mask_ld : 0;
     p.mask_pre = (d->flags & RTN_CONV_MASK_PRE) ? 1 : 0;
     p.ncb = ncb; p.S = S; p.gps = G / S; p.nitems = (int)items;
-    p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;       // A/B knob: 0 = workgroup b starts at item b
-    p.kh_fast = rtn_env_int("RTN_CONV_H8_KHFAST", 1) != 0;
+    p.xcd = 1;                                         // XCD-contiguous item order (0 = workgroup b starts at item b: round-2 A/B, 274 -> 202 MB fetched per tower launch)
+    p.kh_fast = 1;                                     // the kernel rows of a channel chunk back to back (round-2 A/B: profiles/r2_v3_ab_xcd_item_order.txt)
     p.slab = S > 1 ? ws : nullptr;
     p.slab_slice_bytes = S > 1 ? (unsigned)slice_bytes : 0u;
     p.slab_ld = (int)slab_ld;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
         }
         st_ring = st_ring == 2 * Cfg::STAGE ? 0u : st_ring + Cfg::STAGE;
         // kernel rows of a channel chunk back to back: the image rows a tile re-reads for kh = 0, 1, 2 are then one stage apart and
-        // still in the XCD's L2 (RTN_CONV_H8_KHFAST=0: chunks of a kernel row back to back, A/B)
+        // still in the XCD's L2
         if (p.kh_fast) {
             if (++st_kh == 3) {
                 st_kh = 0;
@@ -381,8 +381,8 @@ int rtn_conv_halon_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     p.out_ld = d->out_ld;
     p.pix_b = d->pix_stride * 2;
     p.vec = vec ? 1 : 0;
-    p.xcd = rtn_env_int("RTN_CONV_XCD", 1) != 0;
-    p.kh_fast = rtn_env_int("RTN_CONV_H8_KHFAST", 1) != 0;
+    p.xcd = 1;
+    p.kh_fast = 1;
     int grid = cus;
     if (grid_limit > 0 && grid_limit < grid) grid = grid_limit;
     if (grid > p.ntiles) grid = p.ntiles;

@@ -460,19 +460,9 @@ int rtn_wgrad_win_try(rtn_handle_t h, const rtn_conv_desc_t* d, float* dW, float
         }                                                                                                                         \
         hipLaunchKernelGGL((conv_wgrad_win_kernel<E_, PS_>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);              \
     } while (0)
-    const int dbg = rtn_env_int("RTN_WGRAD_WIN_DBG", 0);    // timing experiments (wrong results): 1 no staging in the loop, 2 no fragment reads / MFMAs
-    if (!ps && rtn_env_int("RTN_WGRAD_WIN_STAGGER", 1) == 0) {       // A/B: every wave stages right behind the barrier
-        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */
-        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {
-            RTN_HIP(h, hipFuncSetAttribute((const void*)conv_wgrad_win_kernel<0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_MAX));
-            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);
-        }
-        hipLaunchKernelGGL((conv_wgrad_win_kernel<0, false, false>), dim3(grid), dim3(WW_THREADS), lds_bytes, h->stream, p);
-    } else if (ps) {
-        if (dbg == 1) RTN_WW_LAUNCH(1, true); else if (dbg == 2) RTN_WW_LAUNCH(2, true); else if (dbg == 3) RTN_WW_LAUNCH(3, true); else RTN_WW_LAUNCH(0, true);
-    } else {
-        if (dbg == 1) RTN_WW_LAUNCH(1, false); else if (dbg == 2) RTN_WW_LAUNCH(2, false); else if (dbg == 3) RTN_WW_LAUNCH(3, false); else RTN_WW_LAUNCH(0, false);
-    }
+    // (timing ablations EXP = 1 / 2 / 3 and the unstaggered staging were round-3 A/Bs: profiles/r3_wgrad_win_ab.txt; only the
+    // production instances are built)
+    if (ps) RTN_WW_LAUNCH(0, true); else RTN_WW_LAUNCH(0, false);
 #undef RTN_WW_LAUNCH
     RTN_CHECK_LAUNCH(h, "conv_wgrad_win_kernel");
     const rtn_wgrad_frag_t fr = {p.ncb, p.C, Ktot, ps ? 4 : 8, ps ? 64 : 128};

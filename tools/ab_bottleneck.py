@@ -15,7 +15,7 @@ variants = [{"RTN_BNECK_THREADS": t, "RTN_BNECK_ROWPP": "0", "RTN_BNECK_DBG": "0
 if "--phase" in sys.argv:         # start delay per wave index (x 64 cycles)
     raise SystemExit("--phase: the per-wave start delay experiment (no effect, profiles/r2_v2_bottleneck_fused.txt) was removed from the kernel")
 if "--ablate" in sys.argv:        # which stream bounds the kernel: drop one at a time (timing only, outputs are wrong)
-    variants = [{"RTN_BNECK_THREADS": "512", "RTN_BNECK_ROWPP": "0", "RTN_BNECK_DBG": d} for d in ("0", "1", "2", "4", "8", "3", "12", "15")]
+    raise SystemExit("the RTN_BNECK_DBG ablation masks left the library in round 4: profiles/r2_v2_bottleneck_fused.txt holds the result")
 
 
 def timed(fn, n=5):

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch, bench
 E = importlib.import_module(bench.PKG + ".engine"); Wt = importlib.import_module(bench.PKG + ".weights"); L = importlib.import_module(bench.PKG + "._lib")
 layers = sys.argv[1].split(",") if len(sys.argv) > 1 else ["pyramid_regression_1"]
-variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_CONV_IMPL=1", "RTN_CONV_IMPL=2+RTN_CONV_IL=0", "RTN_CONV_IMPL=2+RTN_CONV_IL=1"])]
+variants = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["RTN_CONV_IMPL=1", "RTN_CONV_IMPL=2"])]
 state = Wt.init_state("resnet50", 1, 9, seed=0, randomize_bn=True, cls_bias=bench.CLS_BIAS, tame=True)
 eng = E.Engine("resnet50", 1, 9, dtype="bf16"); eng.load_state(state)
 x = bench.synth_images(torch, bench.BATCH, 1000, "cuda")
