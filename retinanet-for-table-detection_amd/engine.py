@@ -88,6 +88,7 @@ class Engine:
         # detect() with `in_flight` > 1: consecutive batches run on `in_flight` buffer sets, each on ONE HIP stream of its own, so the
         # next batch's backbone fills the CUs the current batch's small-M layers and kernel tails leave idle (see detect()).
         self.in_flight = 1
+        self.last_slot = 0
         self.trace_in_flight = None
         self._slots, self._next_slot = [], 0
         self.on_plan_evict = []        # weakref.WeakMethod callbacks key -> None (a Trainer drops its backward plan of the same canvas)
@@ -844,6 +845,7 @@ class Engine:
             self._next_slot = 0
         si = self._next_slot
         self._next_slot = (si + 1) % self.in_flight
+        self.last_slot = si                                  # wait_slot(last_slot): the host waits for THIS batch only
         slot = self._slots[si]
         if self._fp8_on() and self._w8_version != self.weights_version:
             self.join()
@@ -931,6 +933,11 @@ class Engine:
         while len(chosen) < n:                                       # (no overlapping set found: the batches still run, one queue at a time)
             chosen.append(torch.cuda.Stream(device=self.device))
         return chosen
+
+    def wait_slot(self, si):
+        """The HOST waits until the batch most recently given to buffer set `si` is done (its outputs may then be copied out)."""
+        if 0 <= si < len(self._slots) and self._slots[si]["done"] is not None:
+            self._slots[si]["done"].synchronize()
 
     def join(self):
         """The caller's current stream waits for every batch detect() has in flight (in_flight > 1)."""

@@ -113,6 +113,52 @@ class Model:
 
     predict = predict_on_batch
 
+    def predict_generator(self, generator, steps=None, in_flight=2, **kwargs):
+        """keras.Model.predict_generator for the inference model (retinanet_bbox, model/defineModel.py:296-353): the batches of
+        `generator` (a Sequence - generator[i] -> inputs or (inputs, targets) - or any iterable of them) run with `in_flight`
+        batches on the device at a time (Engine.in_flight: the next batch's backbone fills the CUs the current batch's small layers
+        leave idle, + 15 % pages per second at batch 8); every batch's [boxes, scores, labels] are copied out as soon as THAT batch
+        is done.  Returns the three arrays concatenated over the batches (Keras semantics).  RetinaNet.py's test() calls
+        predict_on_batch page by page; a caller with many pages gets this instead."""
+        if not self.bbox:
+            raise ValueError("predict_generator: the inference model (retinanet_bbox) - the training model's outputs go through predict_on_batch")
+        from collections import deque
+        eng = self.engine()
+        n = len(generator) if (steps is None and hasattr(generator, "__len__")) else steps
+        it = (generator[i] for i in range(n)) if hasattr(generator, "__getitem__") and n is not None else iter(generator)
+        outs, pending = ([], [], []), deque()
+
+        def fetch():
+            slot, views = pending.popleft()
+            eng.wait_slot(slot)
+            for o, v in zip(outs, views):
+                o.append(_rt.host(v).copy())
+        prev = eng.in_flight
+        eng.join()
+        eng.in_flight = max(1, int(in_flight))
+        try:
+            for k, item in enumerate(it):
+                if n is not None and k >= n:
+                    break
+                x = item[0] if isinstance(item, (tuple, list)) else item
+                x = _rt.dev(x, torch.float32) if not (isinstance(x, np.ndarray) and x.dtype == np.uint8) else _rt.dev(x, torch.uint8)
+                if eng.in_flight == 1:
+                    views = eng.detect(x)
+                    torch.cuda.current_stream().synchronize()
+                    for o, v in zip(outs, views):
+                        o.append(_rt.host(v).copy())
+                    continue
+                if len(pending) == eng.in_flight:            # its buffer set is the one the next call rewrites
+                    fetch()
+                views = eng.detect(x)
+                pending.append((eng.last_slot, views))
+            while pending:
+                fetch()
+        finally:
+            eng.join()
+            eng.in_flight = prev
+        return [np.concatenate(o, axis=0) if o else np.zeros((0,)) for o in outs]
+
     def train_on_batch(self, x, y):
         tr = self._get_trainer()
         total, reg, cls = tr.train_on_batch(_rt.dev(x, torch.float32), _rt.dev(y[0], torch.float32), _rt.dev(y[1], torch.float32),

@@ -233,3 +233,20 @@ def test_config0_test_image_flow_on_a_sample_sized_page(M, tmp_path):
         n = int((scores[0] >= 0.5).sum())
         assert n > 0 and len(kept) == n and names == sorted("sample_0717_023_%d.jpg" % k for k in range(n))
         assert all(np.array_equal(k[0], (boxes[0, i] / scale).astype(int)) for i, k in enumerate(kept))
+
+
+def test_predict_generator_pipelines_batches_and_matches_predict_on_batch(M):
+    """keras.Model.predict_generator on the inference model with two batches in flight (Engine.in_flight): five batches of pages, of
+    two different canvases, must give exactly what predict_on_batch gives batch by batch (model/defineModel.py:296-353)."""
+    D = M.defineModel
+    model = D.ResNetBackbone("resnet50").retinanet(1, num_anchors=None, modifier=None)
+    bbox = D.retinanet_bbox(model=model)
+    rng = np.random.RandomState(3)
+    batches = [rng.randint(0, 256, (2, 128 + 32 * (i % 2), 160, 3)).astype(np.uint8) for i in range(5)]
+    want = [bbox.predict_on_batch(b) for b in batches]
+    got = bbox.predict_generator(batches, in_flight=2)
+    for k in range(3):
+        assert np.array_equal(got[k], np.concatenate([w[k] for w in want], axis=0))
+    one = bbox.predict_generator(batches[:2], in_flight=1)
+    for k in range(3):
+        assert np.array_equal(one[k], np.concatenate([w[k] for w in want[:2]], axis=0))
