@@ -464,7 +464,7 @@ def main():
         # the solo duration of the dominant kernel (the head-tower layers: the largest share of GPU time).
         plan = eng._plan(BATCH, CANVAS[0], CANVAS[1])
         active = eng.active_ops(plan)
-        conv_ops = [op for op in active if op[0] in ("conv", "dual", "bneck")]
+        conv_ops = [op for op in active if op[0] in ("conv", "dual", "bneck", "chain")]
         fused_stem = any(op[0] == "stem" for op in active)          # conv1 + ReLU + pool1 in one kernel: its MFMA work is conv1's
         stem_conv = [op for op in plan["ops"] if op[0] == "conv" and op[2] == "conv1"][0]
         # a "dual" launch is branch2c with the projection shortcut appended along K: the same FLOPs as the two layers it replaces
@@ -472,6 +472,8 @@ def main():
             if op[0] == "bneck":             # branch2b (3x3, 64 -> 64) + branch2c (64 -> 256) [+ the next branch2a (256 -> 64)]
                 m = op[3]
                 return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + (256 * 64 if (m["tail"] or m.get("proj")) else 0))
+            if op[0] == "chain":             # branch2c (mid -> 4 mid) + the next branch2a (4 mid -> mid)
+                return 2.0 * op[3]["pixels"] * 2 * op[3]["mid"] * 4 * op[3]["mid"]
             return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
         flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         stem_op = [op for op in active if op[0] == "stem"]
@@ -482,8 +484,8 @@ def main():
         achieved = flops_step / (ms_per_step * 1e-3) / 1e12
         reps = 3
         per_op_ms = eng.profile_ops(x, reps=reps)
-        serial_conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem", "dual", "bneck")) / reps
-        serial_other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem", "dual", "bneck")) / reps
+        serial_conv_ms = sum(ms for kind, ms in per_op_ms if kind in ("conv", "stem", "dual", "bneck", "chain")) / reps
+        serial_other_ms = sum(ms for kind, ms in per_op_ms if kind not in ("conv", "stem", "dual", "bneck", "chain")) / reps
         tower = [(op, ms / reps) for op, (kind, ms) in zip(active, per_op_ms[:len(active)])
                  if op[0] == "conv" and op[2].startswith(("pyramid_regression_", "pyramid_classification_"))]
         dom = None
@@ -506,6 +508,9 @@ def main():
                 if m.get("proj"):            # a_in + the block input in, x_out out, branch2b + the K-concatenated [branch2c | branch1] filters
                     return 2.0 * (px * (64 + 64 + 256) + 576 * 64 + 128 * 256)
                 return 2.0 * (px * (64 + 256 + 256 + (64 if m["tail"] else 0)) + 576 * 64 + 64 * 256 + (256 * 64 if m["tail"] else 0))
+            if op[0] == "chain":             # branch2b's output + shortcut in, x_out + a_out out, the two filters
+                m = op[3]
+                return 2.0 * (m["pixels"] * 10 * m["mid"] + 8 * m["mid"] * m["mid"])
             return conv_bytes(op[1], BATCH) + ((BATCH * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
         bytes_step = sum(op_bytes(op) for op in conv_ops)
         n_launch = len(conv_ops) + (1 if fused_stem else 0)

@@ -237,6 +237,30 @@ typedef struct {
 } rtn_bottleneck_desc_t;
 int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d);
 
+/* The seam between two keras_resnet identity bottleneck blocks of the 128- / 256-channel stages (res3b..d, res4b..f) as ONE
+ * launch (inference and training forward, bf16):
+ *   x_out = relu(conv1x1(h_in;  w2c) + b2c + x_in)          this block's branch2c + BN + Add + ReLU   (mid -> out = 4 mid)
+ *   a_out = relu(conv1x1(x_out; w2a) + b2a)                 the NEXT block's branch2a + BN + ReLU     (out -> next = mid)
+ * (keras_resnet bottleneck_2d as instantiated by model/defineModel.py:376-380; replaces one rtn_conv2d_fwd with
+ * RTN_CONV_RES_SAME | RTN_CONV_RELU and the rtn_conv2d_fwd + RTN_CONV_RELU behind it.)  Both tensors are written; x_out is not read
+ * back.  Tensors are dense [pixels][channels] bf16 (NHWC with batch x H x W flattened: the two convs are pointwise, stride 1),
+ * weights [N][K] K-contiguous, biases f32.  Roundings are those of the two separate launches (x_out is rounded to bf16 before it is
+ * multiplied again) and so is the f32 summation order: the results are bit-identical to them.
+ * Built for (mid, out, next) = (128, 512, 128) and (256, 1024, 256): rtn_chain1x1_supported. */
+typedef struct {
+    const void* h_in;  int64_t h_in_elems;    /* [pixels][mid]                            */
+    const void* x_in;  int64_t x_in_elems;    /* [pixels][out]   shortcut                 */
+    void*       x_out; int64_t x_out_elems;   /* [pixels][out]                            */
+    void*       a_out; int64_t a_out_elems;   /* [pixels][next]                           */
+    const void* w2c;   const float* b2c;      /* [out][mid],  [out]                       */
+    const void* w2a;   const float* b2a;      /* [next][out], [next]                      */
+    int64_t pixels;
+    int32_t mid, out, next;
+    int32_t dtype;                             /* RTN_BF16                                 */
+} rtn_chain_desc_t;
+int rtn_chain1x1_fwd(rtn_handle_t h, const rtn_chain_desc_t* d);
+int rtn_chain1x1_supported(int mid, int out, int next);
+
 /* Data gradient (what TF autodiff emits as Conv2DBackpropInput under fit_generator, RetinaNet.py:280).  The same
  * implicit GEMM run on dY: `in` = dY, `w` = the forward weights re-packed by rtn_pack_dgrad_weights
  * (w_d[c][(KH-1-kh, KW-1-kw, n)] = w[n][(kh,kw,c)]), pad = K-1-pad_fwd, stride 1 (a stride-2 1x1 forward conv uses

@@ -84,6 +84,15 @@ class BottleneckDesc(C.Structure):
     ]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [
+        ("h_in", C.c_void_p), ("h_in_elems", C.c_int64), ("x_in", C.c_void_p), ("x_in_elems", C.c_int64),
+        ("x_out", C.c_void_p), ("x_out_elems", C.c_int64), ("a_out", C.c_void_p), ("a_out_elems", C.c_int64),
+        ("w2c", C.c_void_p), ("b2c", C.c_void_p), ("w2a", C.c_void_p), ("b2a", C.c_void_p),
+        ("pixels", C.c_int64), ("mid", C.c_int32), ("out", C.c_int32), ("next", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 class ConvFp8(C.Structure):
     _fields_ = [("acc_scale", C.c_float), ("out_scale", C.c_float), ("out_dtype", C.c_int32)]
 
@@ -108,6 +117,8 @@ SIGNATURES = {
     "rtn_debug_last_conv_tile": (_I, [_P]),
     "rtn_debug_conv_sync_timeouts": (_I, [_P, _P, C.POINTER(C.c_uint32)]),
     "rtn_bottleneck64_fwd": (_I, [_P, C.POINTER(BottleneckDesc)]),
+    "rtn_chain1x1_fwd": (_I, [_P, C.POINTER(ChainDesc)]),
+    "rtn_chain1x1_supported": (_I, [_I, _I, _I]),
     "rtn_conv2d_dgrad": (_I, [_P, C.POINTER(ConvDesc)]),
     "rtn_pack_dgrad_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I]),
     "rtn_pack_dgrad_weights_multi": (_I, [_P, _P, _I, _I64, _I]),

@@ -15,7 +15,8 @@
 //
 // Work decomposition: a wave owns a strip of 32 consecutive pixels (two 16-pixel column fragments) and runs the whole chain on it;
 // waves never synchronise (the only shared data, the weights, is read-only).  The 3x3's input fragments come straight from global
-// memory (16 B per lane: pixel x tap x 8 channels; padding taps get an out-of-range buffer offset = zeros), the shortcut likewise.
+// memory (16 B per lane: pixel x tap x 8 channels; padding taps get an out-of-range buffer offset = zeros; only the centre column
+// of the taps is loaded, the left / right ones are lane shifts of it - "shifted taps" below), the shortcut likewise.
 // LDS: 17 weight images of [64 rows][128 B] (9 taps of W2b, 4 output chunks of W2c, 4 k-chunks of W2a') + biases = 137.5 KiB.
 #include "rtn_internal.h"
 #include <cstdlib>
@@ -92,6 +93,12 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 
 // PROJ: the stage's FIRST block (res2a).  Its shortcut is not the block input but branch1 = conv1x1(block input; wproj): four more
 // weight images sit where TAIL keeps the next branch2a's, the two 16-byte fragments of the input pixel (64 channels) are loaded once
 // per strip, and every output chunk gets 16 more MFMAs instead of 4 shortcut loads.  b2c then holds b2c + b1.
+// Shifted taps (round 4; profiles/r4_bottleneck_shifted_taps.txt): the 3x3's left / right taps are not loaded.  In the flattened pixel order the left neighbour of the pixel in lane c is the
+// pixel in lane c - 1, so tap (kh, kw = 0) of a fragment IS tap (kh, 1) of the same fragment moved up one lane (DPP row_shr:1 - a DPP
+// row is the 16 lanes of one k quarter, i.e. the 16 pixels of the fragment), lane 0 taking lane 15 of the fragment before it or,
+// for the strip's first fragment, one extra "edge" load that fetches just the two pixels beside the strip; where the neighbour lies
+// across an image edge (x = 0 / x = W - 1) the tap is zero padding and the lane is cleared.  12 + 6 loads per strip instead of 36:
+// the kernel is bound by the texture addresser (~60 cycles per fragment-shaped load, header), not by VALU issue.
 template <bool TAIL, int BK_THREADS, bool ROWPP, bool PROJ = false>
 __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_kernel(const BkParams p) {
     static_assert(!(TAIL && PROJ), "the 17 weight images hold either the next branch2a or the projection shortcut");
@@ -167,25 +174,60 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
             g.aoff[u] = (live && !(p.dbg & 8)) ? (unsigned)pix * 128u + (unsigned)q * 16u : BK_OOB;
         }
     };
+    // a tap row in registers: the centre tap + the edge pixels
+    struct Row { uint4 v[1][2][2]; uint4 e[2]; };       // v[0][k half][u]; e[k half]: lane 0 = pixel left of the strip, lane 15 = right of it
 #define BK_LOAD_ROW(KH, G, DST)                                                                      \
-    _Pragma("unroll") for (int kw_ = 0; kw_ < 3; ++kw_) {                                            \
-        const int delta_ = (((KH) - 1) * p.W + (kw_ - 1)) * 128;                                     \
+    {                                                                                                \
+        const int delta_ = ((KH) - 1) * p.W * 128;                                                   \
         _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
-            const unsigned off_ = ((G.okmask[u_] >> ((KH) * 3 + kw_)) & 1u) ? G.pbase[u_] + (unsigned)delta_ : BK_OOB; \
+            const unsigned off_ = ((G.okmask[u_] >> ((KH) * 3 + 1)) & 1u) ? G.pbase[u_] + (unsigned)delta_ : BK_OOB; \
             _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                    \
                 const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off_, ks_ * 64, 0); \
-                DST[kw_][ks_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                              \
+                DST.v[0][ks_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                              \
             }                                                                                        \
         }                                                                                            \
+        const unsigned eoff_ = c == 0 ? (((G.okmask[0] >> ((KH) * 3 + 0)) & 1u) ? G.pbase[0] + (unsigned)(delta_ - 128) : BK_OOB)  \
+                             : c == 15 ? (((G.okmask[1] >> ((KH) * 3 + 2)) & 1u) ? G.pbase[1] + (unsigned)(delta_ + 128) : BK_OOB) : BK_OOB; \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                        \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)eoff_, ks_ * 64, 0); \
+            DST.e[ks_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                         \
+        }                                                                                            \
     }
-#define BK_MUL_ROW(KH, SRC)                                                                          \
-    _Pragma("unroll") for (int kw_ = 0; kw_ < 3; ++kw_)                                              \
+    // lane c <- lane c - 1 of `cur` within each 16-lane row; lane 0 <- `first` as it stands (left) / lane c <- lane c + 1, lane 15 <- `last`
+#define BK_DPP(OLD, SRC, CTRL) (unsigned)__builtin_amdgcn_update_dpp((int)(OLD), (int)(SRC), (CTRL), 0xf, 0xf, false)
+    auto shift_right = [&](const uint4& first, const uint4& cur) {     // result lane c = cur lane c - 1; lane 0 = first lane 0
+        return make_uint4(BK_DPP(first.x, cur.x, 0x111), BK_DPP(first.y, cur.y, 0x111), BK_DPP(first.z, cur.z, 0x111), BK_DPP(first.w, cur.w, 0x111));
+    };
+    auto shift_left = [&](const uint4& last, const uint4& cur) {       // result lane c = cur lane c + 1; lane 15 = last lane 15
+        return make_uint4(BK_DPP(last.x, cur.x, 0x101), BK_DPP(last.y, cur.y, 0x101), BK_DPP(last.z, cur.z, 0x101), BK_DPP(last.w, cur.w, 0x101));
+    };
+    auto rotate = [&](const uint4& v, int ctrl) {                      // 0x121: lane 0 <- lane 15; 0x12f: lane 15 <- lane 0
+        return ctrl == 0x121 ? make_uint4(BK_DPP(0, v.x, 0x121), BK_DPP(0, v.y, 0x121), BK_DPP(0, v.z, 0x121), BK_DPP(0, v.w, 0x121))
+                             : make_uint4(BK_DPP(0, v.x, 0x12f), BK_DPP(0, v.y, 0x12f), BK_DPP(0, v.z, 0x12f), BK_DPP(0, v.w, 0x12f));
+    };
+    auto keep_if = [&](const uint4& v, unsigned ok) { return ok ? v : make_uint4(0u, 0u, 0u, 0u); };
+#define BK_MUL_TAP(KH, KW, OPND)                                                                     \
         _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                          \
             _Pragma("unroll") for (int f_ = 0; f_ < 4; ++f_) {                                       \
-                const uint4 wf_ = BK_WFRAG(W2B_OFF + ((KH) * 3 + kw_) * IMG, f_, ks_);               \
-                BK_MFMA(acc1[f_][0], wf_, SRC[kw_][ks_][0]);                                         \
-                BK_MFMA(acc1[f_][1], wf_, SRC[kw_][ks_][1]);                                         \
+                const uint4 wf_ = BK_WFRAG(W2B_OFF + ((KH) * 3 + (KW)) * IMG, f_, ks_);              \
+                BK_MFMA(acc1[f_][0], wf_, OPND[ks_][0]);                                             \
+                BK_MFMA(acc1[f_][1], wf_, OPND[ks_][1]);                                             \
             }
+#define BK_MUL_ROW(KH, SRC, G)                                                                       \
+    {                                                                                                \
+        uint4 nb_[2][2];                                                                             \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                        \
+            nb_[ks_][0] = keep_if(shift_right(SRC.e[ks_], SRC.v[0][ks_][0]), (G.okmask[0] >> ((KH) * 3 + 0)) & 1u);                        \
+            nb_[ks_][1] = keep_if(shift_right(rotate(SRC.v[0][ks_][0], 0x121), SRC.v[0][ks_][1]), (G.okmask[1] >> ((KH) * 3 + 0)) & 1u);   \
+        }                                                                                            \
+        BK_MUL_TAP(KH, 0, nb_)                                                                       \
+        BK_MUL_TAP(KH, 1, SRC.v[0])                                                                  \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                                        \
+            nb_[ks_][0] = keep_if(shift_left(rotate(SRC.v[0][ks_][1], 0x12f), SRC.v[0][ks_][0]), (G.okmask[0] >> ((KH) * 3 + 2)) & 1u);    \
+            nb_[ks_][1] = keep_if(shift_left(SRC.e[ks_], SRC.v[0][ks_][1]), (G.okmask[1] >> ((KH) * 3 + 2)) & 1u);                         \
+        }                                                                                            \
+        BK_MUL_TAP(KH, 2, nb_)                                                                       \
+    }
 #define BK_LOAD_RES(GI, G, DST)                                                                      \
     if (!PROJ)                                                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
@@ -198,7 +240,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     // the middle of the current strip's output chunks (before the stores of chunks 2 and 3), not after them - otherwise every
     // strip begins by waiting for its predecessor's 20 stores to be acknowledged (measured: memory and compute times added up).
     Geo gc, gn;
-    uint4 row0[3][2][2];            // [kw][k half][u]: tap row 0 of the current strip (requested during the previous strip)
+    Row row0;                       // tap row 0 of the current strip (requested during the previous strip)
     uint4 res0[2][2];               // shortcut chunk 0 of the current strip (likewise)
     int strip = wave * (int)gridDim.x + (int)blockIdx.x;
     geometry(strip, gc);
@@ -224,16 +266,16 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 }
         }
         {
-            uint4 row1[3][2][2];
+            Row row1;
             BK_LOAD_ROW(1, gc, row1)
             __builtin_amdgcn_sched_barrier(0);
-            BK_MUL_ROW(0, row0)
+            BK_MUL_ROW(0, row0, gc)
             __builtin_amdgcn_sched_barrier(0);
             BK_LOAD_ROW(2, gc, row0)
             __builtin_amdgcn_sched_barrier(0);
-            BK_MUL_ROW(1, row1)
+            BK_MUL_ROW(1, row1, gc)
             __builtin_amdgcn_sched_barrier(0);
-            BK_MUL_ROW(2, row0)
+            BK_MUL_ROW(2, row0, gc)
             __builtin_amdgcn_sched_barrier(0);
         }
         // ReLU + bf16: the B operand of G2, k half s = fragments 2 s and 2 s + 1
@@ -351,6 +393,8 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     }
 #undef BK_LOAD_RES
 #undef BK_MUL_ROW
+#undef BK_MUL_TAP
+#undef BK_DPP
 #undef BK_LOAD_ROW
 #undef BK_MFMA
 #undef BK_BIAS
@@ -419,32 +463,27 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     const int wgs_needed = (p.nstrips + nt / 64 - 1) / (nt / 64);
     if (grid > wgs_needed) grid = wgs_needed;
     { const int gl = rtn_env_int("RTN_BNECK_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: several strips per wave on small inputs
-#define RTN_BK_LAUNCH(T, NTH, RP)                                                                        \
-    do {                                                                                                 \
-        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                                                                    \
-        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                                                                                 \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, NTH, RP>,                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
-            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                                                                             \
-        }                                                                                                \
-        hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
-    } while (0)
     const bool rowpp = rtn_bneck_rowpp(nt);
+#define RTN_BK_LAUNCH_S(T, NTH, RP, PJ)                                                                   \
+    do {                                                                                                 \
+        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                 \
+        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                  \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, NTH, RP, PJ>,         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
+            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                      \
+        }                                                                                                \
+        hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP, PJ>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
+    } while (0)
     if (proj) {
-        static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */
-        if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {
-            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<false, 512, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));
-            attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);
-        }
-        hipLaunchKernelGGL((bottleneck64_kernel<false, 512, true, true>), dim3((unsigned)grid), dim3(512), BK_LDS, h->stream, p);
+        RTN_BK_LAUNCH_S(false, 512, true, true);
     } else if (nt == 768) {
-        if (rowpp) { if (tail) RTN_BK_LAUNCH(true, 768, true); else RTN_BK_LAUNCH(false, 768, true); }
-        else       { if (tail) RTN_BK_LAUNCH(true, 768, false); else RTN_BK_LAUNCH(false, 768, false); }
+        if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, 768, true, false); else RTN_BK_LAUNCH_S(false, 768, true, false); }
+        else       { if (tail) RTN_BK_LAUNCH_S(true, 768, false, false); else RTN_BK_LAUNCH_S(false, 768, false, false); }
     } else {
-        if (rowpp) { if (tail) RTN_BK_LAUNCH(true, 512, true); else RTN_BK_LAUNCH(false, 512, true); }
-        else       { if (tail) RTN_BK_LAUNCH(true, 512, false); else RTN_BK_LAUNCH(false, 512, false); }
+        if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, 512, true, false); else RTN_BK_LAUNCH_S(false, 512, true, false); }
+        else       { if (tail) RTN_BK_LAUNCH_S(true, 512, false, false); else RTN_BK_LAUNCH_S(false, 512, false, false); }
     }
-#undef RTN_BK_LAUNCH
+#undef RTN_BK_LAUNCH_S
     RTN_CHECK_LAUNCH(h, "bottleneck64_kernel");
     return RTN_OK;
 }

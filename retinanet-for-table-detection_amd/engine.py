@@ -104,6 +104,10 @@ class Engine:
         # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
         # + shortcut -> the next block's branch2a)
         self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
+        # inference / bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
+        # 256-channel stages (rtn_chain1x1_fwd)
+        # (bit 0: the 128-channel stage, bit 1: the 256-channel stage)
+        self.fuse_chain = int(os.environ.get("RTN_FUSE_CHAIN", "3")) & 3
         self.weights_version = 0
         self.load_epoch = 0            # bumped by load_state(): a live Trainer re-derives its master copy / plans from it
         self._dual, self._dual_version = {}, -1
@@ -359,6 +363,19 @@ class Engine:
         name = blk["n2b"] + "+2c" + ("+next2a" if nxt is not None else "")
         return ("bneck", d, name, {"xs": [a, x], "ys": outs, "B": B, "H": blk["Ho"], "W": blk["Wo"], "tail": nxt is not None, "h1": keep_h1})
 
+    def _chain_op(self, sm):
+        """The seam between two identity blocks of the 128- / 256-channel stages as one launch (rtn_chain1x1_fwd): branch2c + Add +
+        ReLU of the first, branch2a + ReLU of the second."""
+        w2c, b2c = self.w[sm["n2c"]][:2]
+        w2a, b2a = self.w[sm["n2a"]][:2]
+        h, x, y, a = sm["b2"], sm["x"], sm["y"], sm["a"]
+        d = L.ChainDesc()
+        d.h_in, d.h_in_elems, d.x_in, d.x_in_elems = h.data_ptr(), h.numel(), x.data_ptr(), x.numel()
+        d.x_out, d.x_out_elems, d.a_out, d.a_out_elems = y.data_ptr(), y.numel(), a.data_ptr(), a.numel()
+        d.w2c, d.b2c, d.w2a, d.b2a = w2c.data_ptr(), b2c.data_ptr(), w2a.data_ptr(), b2a.data_ptr()
+        d.pixels, d.mid, d.out, d.next, d.dtype = y.numel() // y.shape[3], sm["f"], 4 * sm["f"], sm["f"], self.rdt
+        return ("chain", d, sm["n2c"] + "+next2a", {"xs": [h, x], "ys": [y, a], "pixels": int(d.pixels), "mid": sm["f"]})
+
     # ------------------------------------------------------------------ plan
     def _plan(self, B, H, W, slot=0):
         fp8_on = self._fp8_on()
@@ -428,6 +445,8 @@ class Engine:
         feats = []
         first_blocks = []
         blocks64 = []                    # identity blocks of the 64-channel stage: candidates for the fused bottleneck kernel
+        seams = []                       # identity block -> next block in the 128- / 256-channel stages: branch2c + next branch2a as one launch
+        prev_blk = None
         a_acts = {}
         for stage, nblocks in enumerate(Wt.STAGE_BLOCKS[self.backbone]):
             f = 64 * 2 ** stage
@@ -464,6 +483,14 @@ class Engine:
                 y = buf(B, Ho, Wo, 4 * f)
                 ops.append(self._conv("res%s%s_branch2c" % (s, bname), [self._group(b2, y, Ho, Wo, res=sc)], B,
                                       flags=L.CONV_RELU | L.CONV_RES_SAME))
+                if not (fp8_on and ("a", n2a) in self.fp8_scales):
+                    cur_blk = {"stage": stage, "block": block, "i_2a": i_2a, "i_2c": len(ops) - 1, "a": a, "b2": b2, "x": sc, "y": y, "f": f,
+                               "n2a": n2a, "n2c": "res%s%s_branch2c" % (s, bname)}
+                    if prev_blk is not None and prev_blk["stage"] == stage and prev_blk["block"] >= 1 and prev_blk["block"] + 1 == block \
+                            and L.lib.rtn_chain1x1_supported(f, 4 * f, f):
+                        seams.append({"i_2c": prev_blk["i_2c"], "i_2a": i_2a, "b2": prev_blk["b2"], "x": prev_blk["x"], "y": prev_blk["y"],
+                                      "a": a, "f": f, "n2c": prev_blk["n2c"], "n2a": n2a})
+                    prev_blk = cur_blk
                 if block == 0:
                     first_blocks.append({"key": "res%s%s" % (s, bname), "i_b1": i_b1, "i_2c": len(ops) - 1, "x": x, "b2": b2, "y": y,
                                          "Ho": Ho, "Wo": Wo, "step": st, "f": f, "a": a, "n2b": n2b, "n2a": n2a,
@@ -553,9 +580,16 @@ class Engine:
         for fs in (0, 1, 2):                             # fuse_stem: 1 = conv1 + ReLU + pool1, 2 = ... + res2a_branch2a
             for fd in (False, True):                     # fuse_shortcut
                 for fk in ((0, 1, 2) if bneck_ok else (0,)):      # fuse_bottleneck: 1 = inference, 2 = training (branch2b's output is kept)
-                    if not fs and not fd and not fk:
+                  for fc in ((0, 1, 2, 3) if (bneck_ok and seams) else (0,)):      # fuse_chain: bit 0 = stage 3, bit 1 = stage 4
+                    if not fs and not fd and not fk and not fc:
                         continue
                     v = list(ops)
+                    if fc:
+                        for sm in seams:
+                            if not (fc & (1 if sm["f"] == 128 else 2)):
+                                continue
+                            v[sm["i_2c"]] = self._chain_op(sm)
+                            v[sm["i_2a"]] = None
                     if fd:
                         for fb in first_blocks:
                             v[fb["i_2c"]] = self._dual_op(fb, B)
@@ -581,7 +615,7 @@ class Engine:
                             v[fb0["i_2a"]] = None
                         v = [v[0], sf] + v[n_stem_ops:]                  # pack, then conv1 + ReLU + pool1 as one launch
                     v = [op for op in v if op is not None]
-                    variants[(fs, fd, fk)] = (v, self._schedule(v))
+                    variants[(fs, fd, fk, fc)] = (v, self._schedule(v))
         plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "a_acts": a_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
@@ -608,7 +642,7 @@ class Engine:
             return [op[5].data_ptr()], [op[1].data_ptr(), op[8].data_ptr()] + ([op[7][0].data_ptr()] if op[7] is not None else [])
         if kind == "dual":
             return [t.data_ptr() for t in op[4]["xs"]], [t.data_ptr() for t in op[4]["ys"]]
-        if kind == "bneck":
+        if kind in ("bneck", "chain"):
             return [t.data_ptr() for t in op[3]["xs"]], [t.data_ptr() for t in op[3]["ys"]]
         if kind == "pool":
             return [op[1].data_ptr()], [op[2].data_ptr(), op[4].data_ptr()]
@@ -734,7 +768,8 @@ class Engine:
         if self.fuse_bottleneck and self.dtype == "bf16" and not self._fp8_on():
             fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
         fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and stem16) else 0
-        key = (fs, self.fuse_shortcut, fk)
+        fc = (int(self.fuse_chain) & 3) if (not self.training and self.dtype == "bf16" and not self._fp8_on()) else 0
+        key = (fs, self.fuse_shortcut, fk, fc)
         return key if any(key) else None
 
     def active_ops(self, plan):
@@ -751,6 +786,8 @@ class Engine:
             h.check(lib.rtn_conv1x1_dual_fwd(h.raw, C.byref(op[1]), C.byref(op[3])))
         elif kind == "bneck":
             h.check(lib.rtn_bottleneck64_fwd(h.raw, C.byref(op[1])))
+        elif kind == "chain":
+            h.check(lib.rtn_chain1x1_fwd(h.raw, C.byref(op[1])))
         elif kind == "conv8":
             h.check(lib.rtn_conv2d_fp8_fwd(h.raw, C.byref(op[1]), C.byref(op[4])))
         elif kind == "convq":

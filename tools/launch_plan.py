@@ -34,6 +34,10 @@ for (kind, ms), op in zip(per, ops):
     elif kind == "bneck":
         m = op[3]
         rows.append((name, "fused bottleneck (rtn_bottleneck64_fwd)", "32-pixel strips per wave", "persistent, all filters in LDS", "M %d" % (m["B"] * m["H"] * m["W"]), ms))
+    elif kind == "chain":
+        m = op[3]
+        rows.append((name, "fused seam (rtn_chain1x1_fwd)", "%d-pixel strips per wave" % (32 if m["mid"] == 128 else 16), "persistent, filters streamed through LDS in 64-channel chunks",
+                     "M %d, %d -> %d -> %d" % (m["pixels"], m["mid"], 4 * m["mid"], m["mid"]), ms))
     elif kind == "stem":
         rows.append(("conv1 + ReLU + pool1 + res2a_branch2a", "fused stem (rtn_stem_conv_pool_branch2a)", "4 x 16 pooled pixels", "2 persistent workgroups per CU", "", ms))
     else:
