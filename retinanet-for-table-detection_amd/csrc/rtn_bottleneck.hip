@@ -31,7 +31,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned BK_OOB = 0xFFFF0000u;       // beyond every descriptor (< 2 GiB) even with the largest uniform offset added
 constexpr int IMG = 64 * 128;                          // one weight image: 64 rows x 128 B
 constexpr int W2B_OFF = 0, W2C_OFF = 9 * IMG, W2A_OFF = 13 * IMG, BIAS_OFF = 17 * IMG;
-constexpr int BK_LDS = BIAS_OFF + (64 + 256 + 64) * 4;
+constexpr int XST_OFF = BIAS_OFF + (64 + 256 + 64) * 4;      // per wave 2 KB: the transpose buffer of the line-shaped stores
+constexpr int BK_LDS = XST_OFF + 8 * 2048;
 
 struct BkParams {
     const char* ain;        // [M][64]  bf16: this block's branch2a output (after BN + ReLU)
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
 
     // A-operand (weight) fragment of image `im`, row fragment f, k half ks: lane (kq = q, row c) reads row 16 f + c
     const unsigned w_lane = (unsigned)(c * 128 + ((q ^ (c & 7)) << 4));
+    char* const xl = lds + XST_OFF + wave * 2048;         // this wave's [16 pixels][128 B] transpose buffer (same swizzle)
+    const unsigned xr_lane = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
 #define BK_WFRAG(IMOFF, F, KS) (*reinterpret_cast<const uint4*>(lds + (IMOFF) + (F) * 2048 + (w_lane ^ ((KS) * 64u))))
     const float* bias_l = reinterpret_cast<const float*>(lds + BIAS_OFF);
     // bias of this lane's rows of fragment f (channels 32 (f >> 1) + 8 q + 4 (f & 1) + r, r = 0..3: one float4)
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
         unsigned okmask[2];         // bit (kh * 3 + kw): the tap lies inside the image
         unsigned xoff[2];           // byte offset in a 256-channel tensor (+ this lane's 8-channel group), out of range past M
         unsigned aoff[2];           // byte offset in the 64-channel output
+        unsigned xs[2][2];          // byte offset in the 256-channel output of pixel 16 u + 8 j + (lane >> 3), + 16 (lane & 7)
     };
     auto geometry = [&](int strip, Geo& g) {
         const int p0 = strip * 32;
@@ -172,6 +176,11 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
             g.pbase[u] = (unsigned)pc * 128u + (unsigned)q * 16u;
             g.xoff[u] = live ? (unsigned)pix * 512u + (unsigned)q * 16u : BK_OOB;
             g.aoff[u] = (live && !(p.dbg & 8)) ? (unsigned)pix * 128u + (unsigned)q * 16u : BK_OOB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = p0 + 16 * u + 8 * j + (lane >> 3);
+                g.xs[u][j] = (strip < p.nstrips && px < p.M) ? (unsigned)px * 512u + (unsigned)(lane & 7) * 16u : BK_OOB;
+            }
         }
     };
     // a tap row in registers: the centre tap + the edge pixels
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     if (!PROJ)                                                                                       \
     _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                 \
         _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                           \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((p.dbg & 2) ? BK_OOB : G.xoff[u_]), (GI) * 128 + s_ * 64, 0); \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)G.xoff[u_], (GI) * 128 + s_ * 64, 0); \
             DST[s_][u_] = make_uint4(v_.x, v_.y, v_.z, v_.w);                                        \
         }
     // Software pipeline over the strips of this wave.  vmcnt retires in order, so a load can only be waited for together with
@@ -346,9 +355,9 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
             }
             uint4 xo[2][2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int s = 0; s < 2; ++s) {
                     const f32x4 lo = acc2[2 * s][u], hi = acc2[2 * s + 1][u];
                     const uint4 r = PROJ ? make_uint4(0u, 0u, 0u, 0u) : res[s][u];
                     const uint4 o = make_uint4(pack2(relu(lo[0] + bf_lo(r.x)), relu(lo[1] + bf_hi(r.x))),
@@ -356,10 +365,20 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                                                pack2(relu(hi[0] + bf_lo(r.z)), relu(hi[1] + bf_hi(r.z))),
                                                pack2(relu(hi[2] + bf_lo(r.w)), relu(hi[3] + bf_hi(r.w))));
                     xo[s][u] = o;
-                    const u32x4 ov = {o.x, o.y, o.z, o.w};
-                    __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)((p.dbg & 4) ? BK_OOB : gc.xoff[u]), g * 128 + s * 64, 0);
-                    BK_STORE_GUARD(ov)
+                    *reinterpret_cast<uint4*>(xl + (w_lane ^ (s * 64u))) = o;           // [pixel c][128 B], slot (4 s + q) ^ (c & 7)
                 }
+                {
+                    // the fragment's 16 pixels x 128 B leave as two stores of 8 whole lines each (8 lanes per pixel) instead of two
+                    // stores of 16 half lines: the texture addresser spends ~60 cycles on the latter (header)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint4 o = *reinterpret_cast<const uint4*>(xl + j * 1024 + xr_lane);
+                        const u32x4 ov = {o.x, o.y, o.z, o.w};
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)gc.xs[u][j], g * 128, 0);
+                        BK_STORE_GUARD(ov)
+                    }
+                }
+            }
             if (TAIL) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
 }
 
 int rtn_bneck_threads() {
-    return rtn_env_int("RTN_BNECK_THREADS", 512) == 768 ? 768 : 512;       // 220 VGPRs with the cross-strip prefetch: two waves per SIMD
+    return 512;                                          // (the 768-thread instances left in round 4: slower with the shifted taps, and the LDS now holds the store buffers)
 }
 bool rtn_bneck_rowpp(int nt) {                           // cross-strip software pipeline (RTN_BNECK_ROWPP=0: off, for the A/B)
     return rtn_env_int("RTN_BNECK_ROWPP", 1) != 0;
@@ -464,24 +483,21 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     if (grid > wgs_needed) grid = wgs_needed;
     { const int gl = rtn_env_int("RTN_BNECK_GRID", 0); if (gl > 0 && gl < grid) grid = gl; }     // tests: several strips per wave on small inputs
     const bool rowpp = rtn_bneck_rowpp(nt);
-#define RTN_BK_LAUNCH_S(T, NTH, RP, PJ)                                                                   \
+#define RTN_BK_LAUNCH_S(T, RP, PJ)                                                                       \
     do {                                                                                                 \
         static std::atomic<unsigned long long> attr_set{0ull};  /* one bit per device */                 \
         if (!((attr_set.load(std::memory_order_relaxed) >> (h->device & 63)) & 1ull)) {                  \
-            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, NTH, RP, PJ>,         \
+            RTN_HIP(h, hipFuncSetAttribute((const void*)bottleneck64_kernel<T, 512, RP, PJ>,         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS));         \
             attr_set.fetch_or(1ull << (h->device & 63), std::memory_order_relaxed);                      \
         }                                                                                                \
-        hipLaunchKernelGGL((bottleneck64_kernel<T, NTH, RP, PJ>), dim3((unsigned)grid), dim3(NTH), BK_LDS, h->stream, p); \
+        hipLaunchKernelGGL((bottleneck64_kernel<T, 512, RP, PJ>), dim3((unsigned)grid), dim3(512), BK_LDS, h->stream, p); \
     } while (0)
     if (proj) {
-        RTN_BK_LAUNCH_S(false, 512, true, true);
-    } else if (nt == 768) {
-        if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, 768, true, false); else RTN_BK_LAUNCH_S(false, 768, true, false); }
-        else       { if (tail) RTN_BK_LAUNCH_S(true, 768, false, false); else RTN_BK_LAUNCH_S(false, 768, false, false); }
+        RTN_BK_LAUNCH_S(false, true, true);
     } else {
-        if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, 512, true, false); else RTN_BK_LAUNCH_S(false, 512, true, false); }
-        else       { if (tail) RTN_BK_LAUNCH_S(true, 512, false, false); else RTN_BK_LAUNCH_S(false, 512, false, false); }
+        if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, true, false); else RTN_BK_LAUNCH_S(false, true, false); }
+        else       { if (tail) RTN_BK_LAUNCH_S(true, false, false); else RTN_BK_LAUNCH_S(false, false, false); }
     }
 #undef RTN_BK_LAUNCH_S
     RTN_CHECK_LAUNCH(h, "bottleneck64_kernel");

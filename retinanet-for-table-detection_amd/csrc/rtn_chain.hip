@@ -283,7 +283,8 @@ extern "C" int rtn_chain1x1_fwd(rtn_handle_t h, const rtn_chain_desc_t* d) {
     p.dbg = rtn_env_int("RTN_CHAIN_DBG", 0);
     p.spread = rtn_env_int("RTN_CHAIN_SPREAD", 1) != 0;
     const int gl = rtn_env_int("RTN_CHAIN_GRID", 0);             // tests: several passes per workgroup on small inputs
-    const int depth = rtn_env_int("RTN_CHAIN_DEPTH", 2);
-    if (d->mid == 128) return depth == 1 ? chain_launch<2, 8, 2, 2, 1>(h, p, gl) : chain_launch<2, 8, 2, 2, 2>(h, p, gl);
-    return depth == 1 ? chain_launch<4, 16, 4, 1, 1>(h, p, gl) : depth == 2 ? chain_launch<4, 16, 4, 1, 2>(h, p, gl) : chain_launch<4, 16, 4, 1, 3>(h, p, gl);
+    // (shortcut fragments two chunks ahead instead of one, and x_out as whole lines through an LDS transpose as in rtn_bottleneck.hip,
+    // measured no faster: this kernel is not bound by bytes in flight or by the texture addresser)
+    if (d->mid == 128) return chain_launch<2, 8, 2, 2, 1>(h, p, gl);
+    return chain_launch<4, 16, 4, 1, 1>(h, p, gl);
 }

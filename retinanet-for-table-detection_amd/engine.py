@@ -106,8 +106,9 @@ class Engine:
         self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
         # inference / bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
         # 256-channel stages (rtn_chain1x1_fwd)
-        # (bit 0: the 128-channel stage, bit 1: the 256-channel stage)
-        self.fuse_chain = int(os.environ.get("RTN_FUSE_CHAIN", "3")) & 3
+        # (bit 0: the 128-channel stage, bit 1: the 256-channel stage - built and bit-exact, but no faster than its two layers at 16-pixel
+        # strips, where the filter stream through the LDS bounds it: off by default, tools/ab_engine.py)
+        self.fuse_chain = int(os.environ.get("RTN_FUSE_CHAIN", "1")) & 3
         self.weights_version = 0
         self.load_epoch = 0            # bumped by load_state(): a live Trainer re-derives its master copy / plans from it
         self._dual, self._dual_version = {}, -1

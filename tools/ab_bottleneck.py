@@ -1,4 +1,4 @@
-"""Same-process A/B of the fused bottleneck kernel's variants (RTN_BNECK_THREADS x RTN_BNECK_ROWPP) on the res2 blocks of the bench
+"""Same-process A/B of the fused bottleneck kernel's variants (RTN_BNECK_ROWPP) on the res2 blocks of the bench
 plan, against the three separate launches they replace.  python tools/ab_bottleneck.py"""
 import importlib, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ eng.detect(x); torch.cuda.synchronize()
 plan = eng._plan(bench.BATCH, *bench.CANVAS)
 fused = [op for op in eng.active_ops(plan) if op[0] == "bneck"]
 plain = {op[2]: op for op in plan["ops"] if op[0] == "conv"}
-variants = [{"RTN_BNECK_THREADS": t, "RTN_BNECK_TAPS": "3"} for t in ("512", "768")]     # (the nine-load form, TAPS=9, left the library: profiles/r4_bottleneck_shifted_taps.txt)
+variants = [{"RTN_BNECK_ROWPP": v} for v in ("1", "0")]     # the cross-strip software pipeline (the tap / store forms of round 4: profiles/r4_bottleneck_shifted_taps.txt)
 if "--phase" in sys.argv:         # start delay per wave index (x 64 cycles)
     raise SystemExit("--phase: the per-wave start delay experiment (no effect, profiles/r2_v2_bottleneck_fused.txt) was removed from the kernel")
 if "--ablate" in sys.argv:        # which stream bounds the kernel: drop one at a time (timing only, outputs are wrong)
@@ -43,6 +43,6 @@ for op in fused:
         if rnd >= 2: times[len(variants)].append(t)
     for i, v in enumerate(variants):
         med = statistics.median(times[i])
-        print("%-28s threads %s taps %s: median %.4f ms  min %.4f  (%.2f TB/s)" % (op[2], v["RTN_BNECK_THREADS"], v["RTN_BNECK_TAPS"], med, min(times[i]), by / med / 1e9))
+        print("%-28s %s: median %.4f ms  min %.4f  (%.2f TB/s)" % (op[2], " ".join("%s=%s" % kv for kv in v.items()), med, min(times[i]), by / med / 1e9))
     med = statistics.median(times[len(variants)])
     print("%-28s separate launches %s: median %.4f ms" % (op[2], "+".join(n.split("_")[1] for n in names), med))

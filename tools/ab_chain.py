@@ -30,7 +30,7 @@ def fused(**env):
         os.environ.update(env)
         h.check(L.lib.rtn_chain1x1_fwd(h.raw, C.byref(d)))
     return run
-VARIANTS = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["RTN_CHAIN_DEPTH=1", "RTN_CHAIN_DEPTH=2"])]
+VARIANTS = [dict(kv.split("=") for kv in v.split("+")) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["RTN_CHAIN_SPREAD=1", "RTN_CHAIN_SPREAD=0"])]
 cases = [("separate", separate)] + [("fused " + " ".join("%s=%s" % kv for kv in v.items()), fused(**v)) for v in VARIANTS]
 times = {name: [] for name, _ in cases}
 for rnd in range(12):
