@@ -104,7 +104,7 @@ class Engine:
         # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
         # + shortcut -> the next block's branch2a)
         self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
-        # inference / bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
+        # bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
         # 256-channel stages (rtn_chain1x1_fwd)
         # (bit 0: the 128-channel stage, bit 1: the 256-channel stage - built and bit-exact, but no faster than its two layers at 16-pixel
         # strips, where the filter stream through the LDS bounds it: off by default, tools/ab_engine.py)
@@ -769,7 +769,8 @@ class Engine:
         if self.fuse_bottleneck and self.dtype == "bf16" and not self._fp8_on():
             fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
         fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and stem16) else 0
-        fc = (int(self.fuse_chain) & 3) if (not self.training and self.dtype == "bf16" and not self._fp8_on()) else 0
+        # (training too: both tensors of a seam are written, which is all the backward pass reads)
+        fc = (int(self.fuse_chain) & 3) if (self.dtype == "bf16" and not self._fp8_on()) else 0
         key = (fs, self.fuse_shortcut, fk, fc)
         return key if any(key) else None
 

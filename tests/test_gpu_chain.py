@@ -136,6 +136,6 @@ def test_engine_with_fused_seams_gives_the_bits_of_separate_layers(pkg, monkeypa
         got[fuse] = [t.clone() for t in plan["feats"]] + [reg.clone(), cls.clone()]
     for a, b in zip(got[False], got[True]):
         assert float(a.float().abs().max()) > 0.01 and torch.equal(a, b)
-    eng.training = True                              # the training forward keeps the layers apart (for now)
-    assert [op[0] for op in eng.active_ops(eng._plan(2, 320, 448))].count("chain") == 0
+    eng.training = True                              # the training forward takes the same fused seams
+    assert [op[0] for op in eng.active_ops(eng._plan(2, 320, 448))].count("chain") == 6
     eng.training = False
