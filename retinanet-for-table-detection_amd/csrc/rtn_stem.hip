@@ -40,6 +40,18 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {          // v_cvt_pk_bf16_f32
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned relu_pk(unsigned w) {                   // v_pk_max_i16 with 0: negative bf16 (and -0) -> +0
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
 
 struct StemParams {
     const char* xp;             // [B][Hp][Wp][4] bf16
@@ -84,24 +96,26 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
         const int n = i / 28, q = i - n * 28;
         *reinterpret_cast<uint4*>(wl + n * W_ROW + q * 16) = *reinterpret_cast<const uint4*>(p.wk + (long long)n * 512 + q * 16);
     }
-    float bn[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bn[j][r] = p.bias ? p.bias[j * 16 + kq * 4 + r] : 0.f;
+    // the folded BN shifts live in the 16-byte pads of the filter rows: float4 #(4 j + kq) = channels 16 j + 4 kq .. + 4 in the pad of row
+    // 4 j + kq (registers are what this kernel is short of)
+    if (t < 16) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) v = (f32x4){p.bias[4 * t], p.bias[4 * t + 1], p.bias[4 * t + 2], p.bias[4 * t + 3]};
+        *reinterpret_cast<f32x4*>(wl + t * W_ROW + 7 * 64) = v;
+    }
     // A2: the branch2a filters in LDS behind the conv tile, rows already permuted: row rho holds filter perm(rho); the shifts of
     // this lane's accumulator rows in registers
     char* w2l = lds + LDS_BYTES;
-    float ba[A2 ? 4 : 1][4];
     if (A2) {
         for (int i = t; i < 64 * 8; i += 256) {
             const int rho = i >> 3, q = i & 7;
             *reinterpret_cast<uint4*>(w2l + rho * W2A_ROW + q * 16) = *reinterpret_cast<const uint4*>(p.w2a + (stem_perm_row(rho) * 64 + q * 8) * 2);
         }
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ba[f][r] = p.b2a[stem_perm_row(16 * f + 4 * kq + r)];
+        if (t < 16) {   // shifts of accumulator fragment f, lane quarter kq (4 consecutive channels from perm(16 f + 4 kq)): pad of row 4 f + kq
+            const int f = t >> 2, kq_ = t & 3;
+            const float* bs = p.b2a + stem_perm_row(16 * f + 4 * kq_);
+            *reinterpret_cast<f32x4*>(w2l + t * W2A_ROW + 128) = (f32x4){bs[0], bs[1], bs[2], bs[3]};
+        }
     }
 
     // workgroup -> tiles: workgroup b runs on XCD b % 8; every XCD walks a contiguous range of tiles (neighbouring tiles share
@@ -167,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
 #pragma unroll
         for (int s = 0; s < SUB_PER_WAVE; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[s][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) acc[s][j] = *reinterpret_cast<const f32x4*>(wl + (4 * j + kq) * W_ROW + 7 * 64);     // bias-initialised, as every conv kernel of the library
 #pragma unroll KH_UNROLL     // A2: the fully unrolled loop hoists all 28 filter fragments and spills beside the branch2a state
-        for (int kh = 0; kh < 7; ++kh) {
+        for (int kh = 0; kh < 7; ++kh) {        // (reading the fragments of row kh + 1 under the MFMAs of row kh measured no faster)
             uint4 bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(wl + (j * 16 + m) * W_ROW + kh * 64 + kq * 16);
@@ -195,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint2 o;
-                if (inside) {
-                    o.x = (unsigned)to_bf16(fmaxf(acc[s][j][0] + bn[j][0], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][1] + bn[j][1], 0.f)) << 16);
-                    o.y = (unsigned)to_bf16(fmaxf(acc[s][j][2] + bn[j][2], 0.f)) | ((unsigned)to_bf16(fmaxf(acc[s][j][3] + bn[j][3], 0.f)) << 16);
-                } else {
-                    o.x = o.y = 0xFF80FF80u;
+                if (inside) {       // round to bf16, then ReLU on the packed pair as a signed 16-bit max with 0 (== ReLU, then round)
+                    o.x = relu_pk(pack_bf16(acc[s][j][0], acc[s][j][1]));
+                    o.y = relu_pk(pack_bf16(acc[s][j][2], acc[s][j][3]));
+                } else {            // outside the conv image: never the maximum.  Every pooling window holds a pixel inside and
+                    o.x = o.y = IDX ? 0xFF80FF80u : 0u;    // ReLU outputs are >= 0, so 0 does what -inf does (IDX keeps -inf: it records WHICH tap won)
                 }
                 *reinterpret_cast<uint2*>(cv + i * CV_PX + j * 32 + kq * 8) = o;
             }
@@ -214,40 +228,49 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int cg = 4 * h + kq;
-            float mx[8];
-            unsigned am[8];                                // IDX: first maximum in (kh, kw) scan order, as rtn_maxpool3x3s2_tfsame_fwd_idx records it
+            uint4 o;
+            if (!IDX) {
+                // non-negative bf16 values order like unsigned 16-bit integers: the 3x3 maximum is 9 x 4 v_pk_max_u16 on the packed tile
+                u16x8 mxp = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 255u; }
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int i = (2 * wave + dy) * CT_W + 2 * m + dx;
+                        const uint4 q = *reinterpret_cast<const uint4*>(cv + i * CV_PX + cg * 16);
+                        mxp = __builtin_elementwise_max(mxp, __builtin_bit_cast(u16x8, q));
+                    }
+                o = __builtin_bit_cast(uint4, mxp);
+            } else {
+                float mx[8];
+                unsigned am[8];                            // first maximum in (kh, kw) scan order, as rtn_maxpool3x3s2_tfsame_fwd_idx records it
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int i = (2 * wave + dy) * CT_W + 2 * m + dx;
-                    const uint4 q = *reinterpret_cast<const uint4*>(cv + i * CV_PX + cg * 16);
-                    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 255u; }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
-                        if (IDX) {
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int i = (2 * wave + dy) * CT_W + 2 * m + dx;
+                        const uint4 q = *reinterpret_cast<const uint4*>(cv + i * CV_PX + cg * 16);
+                        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
                             if (lo > mx[2 * e]) { mx[2 * e] = lo; am[2 * e] = (unsigned)(dy * 3 + dx); }
                             if (hi > mx[2 * e + 1]) { mx[2 * e + 1] = hi; am[2 * e + 1] = (unsigned)(dy * 3 + dx); }
-                        } else {
-                            mx[2 * e] = fmaxf(mx[2 * e], lo);
-                            mx[2 * e + 1] = fmaxf(mx[2 * e + 1], hi);
                         }
                     }
+                if (live) {
+                    uint2 iq;
+                    iq.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+                    iq.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+                    *reinterpret_cast<uint2*>(p.idx + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + cg * 8)) = iq;
                 }
-            if (IDX && live) {
-                uint2 iq;
-                iq.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
-                iq.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
-                *reinterpret_cast<uint2*>(p.idx + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + cg * 8)) = iq;
+                o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
+                o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
+                o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
+                o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
             }
-            uint4 o;
-            o.x = (__float_as_uint(mx[0]) >> 16) | (__float_as_uint(mx[1]) & 0xffff0000u);
-            o.y = (__float_as_uint(mx[2]) >> 16) | (__float_as_uint(mx[3]) & 0xffff0000u);
-            o.z = (__float_as_uint(mx[4]) >> 16) | (__float_as_uint(mx[5]) & 0xffff0000u);
-            o.w = (__float_as_uint(mx[6]) >> 16) | (__float_as_uint(mx[7]) & 0xffff0000u);
             if (!live) o = make_uint4(0u, 0u, 0u, 0u);                     // a pixel past the image: finite operand, never stored
             pooled[h] = o;
             if (live) *reinterpret_cast<uint4*>(p.out + ((((long long)b * p.H2 + py) * p.W2 + px) * 64 + cg * 8)) = o;
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
             f32x4 a2[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                a2[f] = (f32x4){ba[f][0], ba[f][1], ba[f][2], ba[f][3]};
+                a2[f] = *reinterpret_cast<const f32x4*>(w2l + (4 * f + kq) * W2A_ROW + 128);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {       // A fragment f, k half h of lane (kq, m): row 16 f + m, input channels 32 h + 8 kq .. + 8
                     const uint4 wf = *reinterpret_cast<const uint4*>(w2l + (16 * f + m) * W2A_ROW + 64 * h + 16 * kq);
