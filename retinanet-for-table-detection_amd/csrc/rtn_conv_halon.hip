@@ -164,20 +164,21 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
     };
     int st_v = blockIdx.x, st_kh = 0, st_cc = 0;
     unsigned st_ring = 0;                              // LDS offset of the stage being filled
-    auto issue_stage = [&]() {
-        const int dy = st_kh - p.pad_t;
-        const unsigned delta = (unsigned)(dy * st_row_b + st_cc * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (unsigned)(hiy[i] + dy) < (unsigned)st_Hin;
-            dma16(in_srd, ok ? hbase[i] + delta : HN_OOB, 0u, lds_base + st_ring + (unsigned)(wave * 1024 + i * 8192));
-        }
-        const unsigned kcol = (unsigned)((st_kh * 3 * nchunk + st_cc) * 128);
-#pragma unroll
-        for (int d = 0; d < Cfg::BPW; ++d) {
-            const int P = d * 8 + wave;
-            dma16(w_srd, wvoff[d], kcol, lds_base + (P < Cfg::BP ? st_ring + HN_HALO + (unsigned)P * 1024u : Cfg::DUMP));
-        }
+    // one of the Cfg::PP (<= 7) DMA instructions of the stage being filled (pieces 0-3: halo, 4..: weights); advance_stage() after the
+    // last.  A macro with a literal piece number: the descriptor operand of the asm must stay in SGPRs.
+#define HN_ISSUE(I)                                                                                            \
+    if ((I) < 4) {                                                                                             \
+        const int dy_ = st_kh - p.pad_t;                                                                       \
+        const unsigned delta_ = (unsigned)(dy_ * st_row_b + st_cc * 128);                                      \
+        const bool ok_ = (unsigned)(hiy[(I) & 3] + dy_) < (unsigned)st_Hin;                                    \
+        dma16(in_srd, ok_ ? hbase[(I) & 3] + delta_ : HN_OOB, 0u, lds_base + st_ring + (unsigned)(wave * 1024 + ((I) & 3) * 8192)); \
+    } else if ((I) < Cfg::PP) {                                                                                \
+        constexpr int d_ = (I) >= 4 && (I) - 4 < Cfg::BPW ? (I) - 4 : 0;                                       \
+        const unsigned kcol_ = (unsigned)((st_kh * 3 * nchunk + st_cc) * 128);                                 \
+        const int P_ = d_ * 8 + wave;                                                                          \
+        dma16(w_srd, wvoff[d_], kcol_, lds_base + (P_ < Cfg::BP ? st_ring + HN_HALO + (unsigned)P_ * 1024u : Cfg::DUMP)); \
+    }
+    auto advance_stage = [&]() {
         st_ring = st_ring == 2 * Cfg::STAGE ? 0u : st_ring + Cfg::STAGE;
         // kernel rows of a channel chunk back to back: the image rows a tile re-reads for kh = 0, 1, 2 are then one stage apart and
         // still in the XCD's L2
@@ -194,6 +195,10 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
                 stage_tile(tile_of(st_v));
             }
         }
+    };
+    auto issue_stage = [&]() {
+        HN_ISSUE(0) HN_ISSUE(1) HN_ISSUE(2) HN_ISSUE(3) HN_ISSUE(4) HN_ISSUE(5) HN_ISSUE(6)
+        advance_stage();
     };
 
     // bias of this lane's channels 16 f + 4 kq + r
@@ -257,25 +262,41 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::PP) : "memory");
             }
             __builtin_amdgcn_s_barrier();              // every wave's pieces have landed and every wave has left the group before
-            issue_stage();                             // two groups ahead, into the stage the group before read
+            // The stage two groups ahead goes out (into the stage the group before read) BETWEEN this group's six (tap, k half)
+            // steps, one or two DMA instructions behind each step's fragment reads: issued back to back they fill the vector-memory
+            // queue and every wave sat ~750 clocks in issue before its first MFMA, while the queue ran dry under the MFMAs
+            // (profiles/r2_v3_halon_stage_timeline.txt).  The asm DMA is a memory fence to the compiler, so the next step's
+            // fragments are read ahead of it by hand.
             const char* sb = lds + c_ring;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    uint4 fx[2], fw[NF];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) fx[i] = *reinterpret_cast<const uint4*>(sb + (arow[kw][i] ^ (ks * 64u)));
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        fw[f] = *reinterpret_cast<const uint4*>(sb + ((w_lane ^ (ks * 64u)) + (unsigned)((kw * NF + f) * 2048)));
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[f]),
-                                                                               __builtin_bit_cast(bf16x8, fx[i]), acc[i][f], 0, 0, 0);
-                }
+            uint4 fx[2][2], fw[2][NF];
+#define HN_READ(STEP, SET)                                                                                     \
+            {                                                                                                  \
+                const int kw_ = ((STEP) >> 1) % 3;                                                             \
+                const unsigned ks_ = ((STEP) & 1) * 64u;                                                       \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) fx[SET][i] = *reinterpret_cast<const uint4*>(sb + (arow[kw_][i] ^ ks_)); \
+                _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                 \
+                    fw[SET][f] = *reinterpret_cast<const uint4*>(sb + ((w_lane ^ ks_) + (unsigned)((kw_ * NF + f) * 2048))); \
+            }
+#define HN_STEP(STEP)                                                                                          \
+            {                                                                                                  \
+                if ((STEP) + 1 < 6) HN_READ((STEP) + 1, ((STEP) + 1) & 1)                                      \
+                if (0 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(0) }                                                 \
+                if (1 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(1) }                                                 \
+                if (2 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(2) }                                                 \
+                if (3 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(3) }                                                 \
+                if (4 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(4) }                                                 \
+                if (5 < Cfg::PP && 5 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(5) }                                  \
+                if (6 < Cfg::PP && 6 * 6 / Cfg::PP == (STEP)) { HN_ISSUE(6) }                                  \
+                _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                 \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[(STEP) & 1][f]),      \
+                                                                           __builtin_bit_cast(bf16x8, fx[(STEP) & 1][i]), acc[i][f], 0, 0, 0); \
+            }
+            HN_READ(0, 0)
+            HN_STEP(0) HN_STEP(1) HN_STEP(2) HN_STEP(3) HN_STEP(4) HN_STEP(5)
+#undef HN_STEP
+#undef HN_READ
+            advance_stage();
             c_ring = c_ring == 2 * Cfg::STAGE ? 0u : c_ring + Cfg::STAGE;
         }
         // ---- epilogue: channels 16 f + 4 kq .. + 3 of pixel (i, lrow); the same number of store instructions for every wave
@@ -317,6 +338,7 @@ __global__ __launch_bounds__(HN_THREADS, 2) void conv_halon_kernel(const HNParam
         first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+#undef HN_ISSUE
 }
 
 }  // namespace
