@@ -51,7 +51,7 @@ struct BkParams {
     const float* b2a;
     int M, H, W, nstrips;
     float inv_cells, inv_w;
-    int dbg;                // timing ablation only (RTN_BNECK_DBG): 1 drop the 3x3's loads, 2 the shortcut loads, 4 the x_out stores, 8 the a_out stores
+    int dbg;                // always 0 (the round-2 timing ablations: 1 drop the 3x3's loads, 8 the a_out stores; profiles/r2_v2_bottleneck_fused.txt)
 };
 
 __device__ __forceinline__ int perm_row(int rho) {     // MFMA row (16 f + 4 q + r) -> channel 32 (f >> 1) + 8 q + 4 (f & 1) + r
@@ -420,9 +420,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
 #undef BK_WFRAG
 }
 
-int rtn_bneck_threads() {
-    return 512;                                          // (the 768-thread instances left in round 4: slower with the shifted taps, and the LDS now holds the store buffers)
-}
+constexpr int BK_NT = 512;          // (the 768-thread instances left in round 4: slower with the shifted taps, and the LDS now holds the store buffers)
 bool rtn_bneck_rowpp(int nt) {                           // cross-strip software pipeline (RTN_BNECK_ROWPP=0: off, for the A/B)
     return rtn_env_int("RTN_BNECK_ROWPP", 1) != 0;
 }
@@ -476,8 +474,7 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     p.inv_cells = 1.0f / (float)((long long)d->H * d->W);
     p.inv_w = 1.0f / (float)d->W;
     p.dbg = 0;                                         // (timing ablations of round 2: profiles/r2_v2_bottleneck_fused.txt)
-    // 12 waves per CU (154 VGPRs: three per SIMD) keep 1.5 x the loads of 8 in flight; RTN_BNECK_THREADS=512 for the A/B
-    const int nt = rtn_bneck_threads();
+    const int nt = BK_NT;
     int grid = h->num_cus > 0 ? h->num_cus : 256;
     const int wgs_needed = (p.nstrips + nt / 64 - 1) / (nt / 64);
     if (grid > wgs_needed) grid = wgs_needed;
