@@ -43,7 +43,7 @@ def main():
         kernels[name] = {"launches_per_step": round(max(fc.get(name, 0), wc.get(name, 0)) / passes, 3),
                          "fetch_bytes_per_step": int(2 * 1024 * f.get(name, 0.0) / passes),
                          "write_bytes_per_step": int(1024 * w.get(name, 0.0) / passes)}
-    conv = {k: v for k, v in kernels.items() if k.startswith(("conv_", "stem_fused", "bottleneck64"))}
+    conv = {k: v for k, v in kernels.items() if k.startswith(("conv_", "stem_fused", "bottleneck64", "chain1x1"))}
     fb = sum(v["fetch_bytes_per_step"] for v in conv.values())
     wb = sum(v["write_bytes_per_step"] for v in conv.values())
     n = sum(v["launches_per_step"] for v in conv.values())
