@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 TAG=$1; COMMIT=$2; O=gpurun_out/$TAG
 mkdir -p $O
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --in-flight 1"     # the PMC passes count 7.125 batch-8 passes per process
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --in-flight 1"     # (tools/pmc_traffic.py counts the batch-8 passes of the process itself)
 T="python3 bench.py --mode train --steps 3 --warmup 1"
 echo "== kernel trace / stats (inference, the bench default: two batches in flight)"; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/kt2.log 2>&1
 echo "== kernel trace / stats (inference, one batch at a time, lanes on)"; timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --in-flight 1 > $O/kt.log 2>&1
@@ -29,7 +29,7 @@ cp "$(statof kt)" $O/bench_kernel_stats.csv 2>/dev/null
 cp "$(statof kt1)" $O/bench_kernel_stats_one_stream.csv 2>/dev/null
 cp "$(statof ktt)" $O/train_kernel_stats.csv 2>/dev/null
 cp "$(statof ktt1)" $O/train_kernel_stats_one_stream.csv 2>/dev/null
-RTN_GIT_COMMIT=$COMMIT python3 tools/pmc_traffic.py "$(csvof pmc_f)" "$(csvof pmc_w)" 7.125 $O/pmc_traffic.json $O/pmc_f.log > $O/pmc_traffic.txt 2>&1
+RTN_GIT_COMMIT=$COMMIT python3 tools/pmc_traffic.py "$(csvof pmc_f)" "$(csvof pmc_w)" auto $O/pmc_traffic.json $O/pmc_f.log > $O/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma_util.py "$(csvof pmc_m)" "$(csvof pmc_s)" $O/pmc_mfma_util.json > $O/pmc_mfma_util.txt 2>&1
 python3 tools/pmc_train.py "$(csvof pmct_f)" "$(csvof pmct_w)" "$(csvof pmct_m)" 4 16 $COMMIT $O/pmc_train_traffic.json $O/pmc_train_mfma_util.json > $O/pmc_train.txt 2>&1
 echo "== layer times"; timeout -k 10 200 python3 tools/profile_layers.py > $O/layer_times.txt 2>&1
