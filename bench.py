@@ -341,8 +341,8 @@ def bench_train(args, torch, dist, E, Wt, rank, local_rank, world, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the training-step measurement (the `secondary` object)")
     ap.add_argument("--secondary-steps", type=int, default=20)
