@@ -374,7 +374,11 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                     for (int j = 0; j < 2; ++j) {
                         const uint4 o = *reinterpret_cast<const uint4*>(xl + j * 1024 + xr_lane);
                         const u32x4 ov = {o.x, o.y, o.z, o.w};
-                        __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)gc.xs[u][j], g * 128, 0);
+                        // aux 2 = nt: a streaming store.  x_out (273 MB at batch 8) is many times the L2 and is read back by the next
+                        // launch only; without the hint its lines push the tap rows and shortcut lines out of the L2 on their way to
+                        // memory.  Launch alone 0.122 / 0.147 / 0.133 -> 0.102 / 0.140 / 0.123 ms, the step -0.4 % (tools/ab_engine.py);
+                        // the same hint on the shortcut loads changed nothing.
+                        __builtin_amdgcn_raw_buffer_store_b128(ov, o_rsrc, (int)gc.xs[u][j], g * 128, 2);
                         BK_STORE_GUARD(ov)
                     }
                 }
