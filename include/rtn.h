@@ -228,7 +228,8 @@ typedef struct {
     int32_t w2c_ld;                            /* elements between rows of w2c / wproj; 0 = mid (dense)                */
     /* The stage's FIRST block (res2a), whose shortcut is a projection (model/defineModel.py:376-380, keras_resnet
      * bottleneck_2d with block == 0):  x_out = relu(conv1x1(h1; w2c) + conv1x1(p_in; wproj) + b2c)  with b2c = b2c + b1 summed by
-     * the caller and p_in the block input [batch][H][W][mid].  x_in is not read; a_out must be NULL.  With the K-concatenated
+     * the caller and p_in the block input [batch][H][W][mid].  x_in is not read.  With a_out the next block's branch2a rides along
+     * as in the identity form (its filters and the two of this block are then streamed through the LDS chunk by chunk).  With the K-concatenated
      * filters of rtn_conv1x1_dual_fwd ([4*mid][mid + mid]): w2c = that matrix, wproj = w2c + mid elements, w2c_ld = 2 * mid. */
     const void* p_in;  int64_t p_in_elems;
     const void* wproj;

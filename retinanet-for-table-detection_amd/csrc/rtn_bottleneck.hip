@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned BK_OOB = 0xFFFF0000u;       // beyond every descriptor (< 2 GiB) even with the largest uniform offset added
 constexpr int IMG = 64 * 128;                          // one weight image: 64 rows x 128 B
 constexpr int W2B_OFF = 0, W2C_OFF = 9 * IMG, W2A_OFF = 13 * IMG, BIAS_OFF = 17 * IMG;
+constexpr int RING_OFF = 9 * IMG;                      // PROJ + TAIL: two slots of [branch2c | projection | next branch2a] images of one 64-channel chunk
 constexpr int XST_OFF = BIAS_OFF + (64 + 256 + 64) * 4;      // per wave 2 KB: the transpose buffer of the line-shaped stores
 constexpr int BK_LDS = XST_OFF + 8 * 2048;
 
@@ -102,7 +103,12 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 
 // the kernel is bound by the texture addresser (~60 cycles per fragment-shaped load, header), not by VALU issue.
 template <bool TAIL, int BK_THREADS, bool ROWPP, bool PROJ = false>
 __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_kernel(const BkParams p) {
-    static_assert(!(TAIL && PROJ), "the 17 weight images hold either the next branch2a or the projection shortcut");
+    // PROJ && TAIL (res2a with res2b's branch2a appended): 21 images do not fit the LDS, so the three per-chunk filter sets are
+    // STREAMED - chunk g of an output strip needs image g of branch2c, of the projection and of the next branch2a only: a ring of
+    // two 3-image slots, the next chunk's images loaded into registers at the start of a chunk and written to the other slot at its
+    // end, ONE workgroup barrier per chunk (the other forms have none: their waves never synchronise).  Every wave then runs the same
+    // number of strips (a wave without a strip computes on out-of-range offsets: zeros in, nothing out).
+    constexpr bool STREAM = TAIL && PROJ;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -112,9 +118,12 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     {
         const int rho = (t >> 3) & 63, slot = t & 7, chunk = slot ^ (rho & 7), src = perm_row(rho);
 #pragma unroll 1
-        for (int im = 0; im < 17 && t < 512; ++im) {
+        for (int im = 0; im < (STREAM ? 12 : 17) && t < 512; ++im) {
             const char* g = nullptr;
             if (im < 9)       g = p.w2b + ((long long)src * 576 + im * 64) * 2 + chunk * 16;
+            else if (STREAM)  g = im == 9 ? p.w2c + ((long long)src * p.w2c_ld) * 2 + chunk * 16         // chunk 0 into ring slot 0
+                                : im == 10 ? p.wproj + ((long long)src * p.w2c_ld) * 2 + chunk * 16
+                                : p.w2a + ((long long)src * 256) * 2 + chunk * 16;
             else if (im < 13) g = p.w2c + ((long long)((im - 9) * 64 + src) * p.w2c_ld) * 2 + chunk * 16;
             else if (TAIL)    g = p.w2a + ((long long)src * 256 + (im - 13) * 64) * 2 + chunk * 16;
             else if (PROJ)    g = p.wproj + ((long long)((im - 13) * 64 + src) * p.w2c_ld) * 2 + chunk * 16;
@@ -140,6 +149,29 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     char* const xl = lds + XST_OFF + wave * 2048;         // this wave's [16 pixels][128 B] transpose buffer (same swizzle)
     const unsigned xr_lane = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
 #define BK_WFRAG(IMOFF, F, KS) (*reinterpret_cast<const uint4*>(lds + (IMOFF) + (F) * 2048 + (w_lane ^ ((KS) * 64u))))
+    // where chunk G's images sit: resident (image G of the block) or, STREAM, in ring slot G & 1
+#define BK_IMG_2C(G) (STREAM ? RING_OFF + ((G) & 1) * 3 * IMG : W2C_OFF + (G) * IMG)
+#define BK_IMG_PJ(G) (STREAM ? RING_OFF + ((G) & 1) * 3 * IMG + IMG : W2A_OFF + (G) * IMG)
+#define BK_IMG_2A(G) (STREAM ? RING_OFF + ((G) & 1) * 3 * IMG + 2 * IMG : W2A_OFF + (G) * IMG)
+    // STREAM: this thread's piece of the next chunk's three images (row rho of an image <- filter row perm_row(rho), slot swizzled)
+    const int st_rho = (t >> 3) & 63, st_slot = t & 7, st_src = perm_row(st_rho);
+    const unsigned st_loff = (unsigned)(st_rho * 128 + st_slot * 16);
+    const unsigned st_vc = STREAM ? (unsigned)(st_src * p.w2c_ld * 2 + (st_slot ^ (st_rho & 7)) * 16) : 0u;       // row st_src of a [64][w2c_ld] block
+    const unsigned st_va = (unsigned)(st_src * 512 + (st_slot ^ (st_rho & 7)) * 16);                              // row st_src of [64][256]
+    const __amdgpu_buffer_rsrc_t wc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2c, 0, STREAM ? (255 * p.w2c_ld + 64) * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(STREAM ? p.wproj : p.w2c), 0, STREAM ? (255 * p.w2c_ld + 64) * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wa_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(STREAM ? p.w2a : p.w2c), 0, STREAM ? 64 * 256 * 2 : 0, 0x00020000);
+    uint4 wreg[3];
+    auto ring_load = [&](int gn) {
+        const u32x4 a_ = __builtin_amdgcn_raw_buffer_load_b128(wc_rsrc, (int)st_vc, gn * 64 * p.w2c_ld * 2, 0);
+        const u32x4 b_ = __builtin_amdgcn_raw_buffer_load_b128(wp_rsrc, (int)st_vc, gn * 64 * p.w2c_ld * 2, 0);
+        const u32x4 c_ = __builtin_amdgcn_raw_buffer_load_b128(wa_rsrc, (int)st_va, gn * 128, 0);
+        wreg[0] = make_uint4(a_.x, a_.y, a_.z, a_.w); wreg[1] = make_uint4(b_.x, b_.y, b_.z, b_.w); wreg[2] = make_uint4(c_.x, c_.y, c_.z, c_.w);
+    };
+    auto ring_store = [&](int slot_r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<uint4*>(lds + RING_OFF + (slot_r * 3 + k) * IMG + st_loff) = wreg[k];
+    };
     const float* bias_l = reinterpret_cast<const float*>(lds + BIAS_OFF);
     // bias of this lane's rows of fragment f (channels 32 (f >> 1) + 8 q + 4 (f & 1) + r, r = 0..3: one float4)
 #define BK_BIAS(BASE, F) (*reinterpret_cast<const f32x4*>(bias_l + (BASE) + 32 * ((F) >> 1) + 8 * q + 4 * ((F) & 1)))
@@ -256,7 +288,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
     BK_LOAD_ROW(0, gc, row0)
     BK_LOAD_RES(0, gc, res0)
 #pragma unroll 1
-    for (; strip < p.nstrips; strip += stride) {
+    for (; STREAM ? (strip - wave * (int)gridDim.x) < p.nstrips : strip < p.nstrips; strip += stride) {      // STREAM: as long as wave 0 has a strip
         // ---- G1: branch2b.  acc1[f][u] = sum over taps, k of W2b[chan(f)][tap][k] * Ain[pixel(u) + tap][k]
         f32x4 acc1[4][2];
 #pragma unroll
@@ -327,6 +359,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 BK_LOAD_RES(0, gn, res0)
             }
             if (g + 1 < 4) BK_LOAD_RES(g + 1, gc, resq[(g + 1) & 1])
+            if (STREAM) ring_load((g + 1) & 3);
             __builtin_amdgcn_sched_barrier(0);
             uint4 (&res)[2][2] = resq[g & 1];
             f32x4 acc2[4][2];
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    const uint4 wf = BK_WFRAG(W2C_OFF + g * IMG, f, ks);
+                    const uint4 wf = BK_WFRAG(BK_IMG_2C(g), f, ks);
                     BK_MFMA(acc2[f][0], wf, h1[ks][0]);
                     BK_MFMA(acc2[f][1], wf, h1[ks][1]);
                 }
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
-                        const uint4 wf = BK_WFRAG(W2A_OFF + g * IMG, f, ks);
+                        const uint4 wf = BK_WFRAG(BK_IMG_PJ(g), f, ks);
                         BK_MFMA(acc2[f][0], wf, pfrag[ks][0]);
                         BK_MFMA(acc2[f][1], wf, pfrag[ks][1]);
                     }
@@ -388,10 +421,14 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
-                        const uint4 wf = BK_WFRAG(W2A_OFF + g * IMG, f, ks);
+                        const uint4 wf = BK_WFRAG(BK_IMG_2A(g), f, ks);
                         BK_MFMA(acc3[f][0], wf, xo[ks][0]);
                         BK_MFMA(acc3[f][1], wf, xo[ks][1]);
                     }
+            }
+            if (STREAM) {           // the next chunk's images are in registers: into the slot the chunk before read, then everyone meets
+                ring_store((g & 1) ^ 1);
+                __syncthreads();
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -421,6 +458,9 @@ __global__ __launch_bounds__(BK_THREADS, BK_THREADS / 256) void bottleneck64_ker
 #undef BK_LOAD_ROW
 #undef BK_MFMA
 #undef BK_BIAS
+#undef BK_IMG_2C
+#undef BK_IMG_PJ
+#undef BK_IMG_2A
 #undef BK_WFRAG
 }
 
@@ -447,8 +487,8 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
     const bool tail = d->a_out != nullptr;
     const int w2c_ld = d->w2c_ld > 0 ? d->w2c_ld : 64;
     if (w2c_ld < 64 || w2c_ld % 8) return rtn_fail(h, RTN_EINVAL, "bottleneck64: w2c_ld %d", d->w2c_ld);
-    if (proj && (tail || ((uintptr_t)d->wproj & 15) || d->p_in_elems < M * 64))
-        return rtn_fail(h, RTN_EINVAL, "bottleneck64: the projection-shortcut form takes p_in [M][64], an aligned wproj and no a_out");
+    if (proj && (((uintptr_t)d->wproj & 15) || d->p_in_elems < M * 64))
+        return rtn_fail(h, RTN_EINVAL, "bottleneck64: the projection-shortcut form takes p_in [M][64] and an aligned wproj");
     if (tail && (!d->w2a || !d->b2a || ((uintptr_t)d->a_out & 15) || ((uintptr_t)d->w2a & 15) || ((uintptr_t)d->b2a & 15)))
         return rtn_fail(h, RTN_EINVAL, "bottleneck64: a_out needs aligned w2a / b2a");
     if (d->a_in_elems < M * 64 || (!proj && d->x_in_elems < M * 256) || d->x_out_elems < M * 256 || (tail && d->a_out_elems < M * 64))
@@ -495,7 +535,7 @@ extern "C" int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t*
         hipLaunchKernelGGL((bottleneck64_kernel<T, 512, RP, PJ>), dim3((unsigned)grid), dim3(512), BK_LDS, h->stream, p); \
     } while (0)
     if (proj) {
-        RTN_BK_LAUNCH_S(false, true, true);
+        if (tail) RTN_BK_LAUNCH_S(true, true, true); else RTN_BK_LAUNCH_S(false, true, true);
     } else {
         if (rowpp) { if (tail) RTN_BK_LAUNCH_S(true, true, false); else RTN_BK_LAUNCH_S(false, true, false); }
         else       { if (tail) RTN_BK_LAUNCH_S(true, false, false); else RTN_BK_LAUNCH_S(false, false, false); }

@@ -104,6 +104,8 @@ class Engine:
         # inference/bf16: the identity blocks of the 64-channel stage as one kernel each (rtn_bottleneck64_fwd: branch2b -> branch2c
         # + shortcut -> the next block's branch2a)
         self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
+        # ... and res2b_branch2a appended to res2a's fused block (its projection form with the three per-chunk filter sets streamed)
+        self.fuse_proj_tail = os.environ.get("RTN_FUSE_PROJ_TAIL", "1") != "0"
         # bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
         # 256-channel stages (rtn_chain1x1_fwd)
         # (bit 0: the 128-channel stage, bit 1: the 256-channel stage - built and bit-exact, but no faster than its two layers at 16-pixel
@@ -320,9 +322,10 @@ class Engine:
         L.attach_conv_workspace(self.h, d, s2)             # stream-K slabs of the small-M stages (res5a): caller-owned
         return ("dual", d, fb["key"] + "_branch2c+1", s2, {"xs": [fb["b2"], x], "ys": [fb["y"]]})
 
-    def _bneck_proj_op(self, fb, B, keep_h1=False):
+    def _bneck_proj_op(self, fb, B, keep_h1=False, nxt=None):
         """The FIRST block of the 64-channel stage as one launch: branch2b, then branch2c and the projection shortcut as one product
-        over the K-concatenated filters of _dual_weights() (rtn_bottleneck64_fwd with p_in / wproj)."""
+        over the K-concatenated filters of _dual_weights() (rtn_bottleneck64_fwd with p_in / wproj), and branch2a of the following
+        identity block `nxt` when there is one."""
         wd, bd = self._dual_weights()[fb["key"]]
         w2b, b2b = self.w[fb["n2b"]][:2]
         a, x, y = fb["a"], fb["x"], fb["y"]
@@ -334,11 +337,16 @@ class Engine:
         d.wproj, d.w2c_ld = wd.data_ptr() + 64 * wd.element_size(), wd.shape[1]
         d.batch, d.H, d.W, d.mid, d.dtype = B, fb["Ho"], fb["Wo"], 64, self.rdt
         outs = [y]
+        if nxt is not None:
+            w2a, b2a = self.w[nxt["n2a"]][:2]
+            d.a_out, d.a_out_elems = nxt["a"].data_ptr(), nxt["a"].numel()
+            d.w2a, d.b2a = w2a.data_ptr(), b2a.data_ptr()
+            outs.append(nxt["a"])
         if keep_h1:                                      # training: branch2b's activation is an input of the backward pass
             d.h1_out, d.h1_out_elems = fb["b2"].data_ptr(), fb["b2"].numel()
             outs.append(fb["b2"])
-        return ("bneck", d, fb["n2b"] + "+2c+1", {"xs": [a, x], "ys": outs, "B": B, "H": fb["Ho"], "W": fb["Wo"], "tail": False, "proj": True,
-                                                  "h1": keep_h1})
+        return ("bneck", d, fb["n2b"] + "+2c+1" + ("+next2a" if nxt is not None else ""),
+                {"xs": [a, x], "ys": outs, "B": B, "H": fb["Ho"], "W": fb["Wo"], "tail": nxt is not None, "proj": True, "h1": keep_h1})
 
     def _bneck_op(self, blk, nxt, B, keep_h1=False):
         """An identity block of the 64-channel stage as one launch (rtn_bottleneck64_fwd): branch2b + branch2c + Add + ReLU of
@@ -582,6 +590,7 @@ class Engine:
             for fd in (False, True):                     # fuse_shortcut
                 for fk in ((0, 1, 2) if bneck_ok else (0,)):      # fuse_bottleneck: 1 = inference, 2 = training (branch2b's output is kept)
                   for fc in ((0, 1, 2, 3) if (bneck_ok and seams) else (0,)):      # fuse_chain: bit 0 = stage 3, bit 1 = stage 4
+                   for fp in ((0, 1) if (fk and fd) else (0,)):                    # fuse_proj_tail
                     if not fs and not fd and not fk and not fc:
                         continue
                     v = list(ops)
@@ -598,8 +607,11 @@ class Engine:
                     if fk and fd:                            # res2a: branch2b + [branch2c | branch1] + ReLU as one launch
                         for fb in first_blocks:
                             if fb["f"] == 64 and fb["step"] == 1 and fb["i_2b"] is not None:
-                                v[fb["i_2b"]] = self._bneck_proj_op(fb, B, keep_h1=fk == 2)
+                                nx0 = blocks64[0] if (blocks64 and fp) else None      # res2b's branch2a rides along
+                                v[fb["i_2b"]] = self._bneck_proj_op(fb, B, keep_h1=fk == 2, nxt=nx0)
                                 v[fb["i_2c"]] = None
+                                if nx0 is not None:
+                                    v[nx0["i_2a"]] = None
                     if fk:
                         for bi, blk in enumerate(blocks64):
                             nxt = blocks64[bi + 1] if bi + 1 < len(blocks64) else None      # its branch2a rides along
@@ -616,7 +628,7 @@ class Engine:
                             v[fb0["i_2a"]] = None
                         v = [v[0], sf] + v[n_stem_ops:]                  # pack, then conv1 + ReLU + pool1 as one launch
                     v = [op for op in v if op is not None]
-                    variants[(fs, fd, fk, fc)] = (v, self._schedule(v))
+                    variants[(fs, fd, fk, fc, fp)] = (v, self._schedule(v))
         plan = {"ops": ops, "towers": tower_ranges, "tower_acts": tower_acts, "a_acts": a_acts, "fp8": fp8_on, "sched": sched, "keep": keep, "variants": variants, "xin": xin, "cfg": cfg, "N": N, "regression": regression,
                 "classification": classification, "pyr": pyr, "feats": feats,
                 "det_ws": torch.empty(ws_bytes, dtype=torch.uint8, device=dev), "det_ws_bytes": ws_bytes,
@@ -771,7 +783,8 @@ class Engine:
         fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and stem16) else 0
         # (training too: both tensors of a seam are written, which is all the backward pass reads)
         fc = (int(self.fuse_chain) & 3) if (self.dtype == "bf16" and not self._fp8_on()) else 0
-        key = (fs, self.fuse_shortcut, fk, fc)
+        fp = 1 if (self.fuse_proj_tail and fk and self.fuse_shortcut) else 0
+        key = (fs, self.fuse_shortcut, fk, fc, fp)
         return key if any(key) else None
 
     def active_ops(self, plan):

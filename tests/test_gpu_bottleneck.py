@@ -139,9 +139,29 @@ def test_bottleneck64_projection_shortcut_form(pkg, handle, monkeypatch, B, H, W
     handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
     assert torch.equal(first, xout)
-    aout = torch.zeros(B, H, W, 64, dtype=torch.bfloat16, device=dev)
-    d.a_out, d.a_out_elems = aout.data_ptr(), aout.numel()
-    assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1          # no next-branch2a output in this form
+    # ... with the NEXT block's branch2a appended (res2a -> res2b): the three per-chunk filter sets are streamed through the LDS, one
+    # workgroup barrier per chunk; x_out must keep its bits, a_out = relu(conv1x1(x_out; w2a) + b2a)
+    w2a = torch.randn(64, 256, generator=g, dtype=torch.float64) / 16.0
+    b2a = torch.randn(64, generator=g, dtype=torch.float64) * 0.3
+    ao = bf(torch.relu(xo @ bf(w2a).T + b2a.float().double()))
+    wad, bad = t16(w2a), b2a.float().to(dev)
+    aout = torch.full((B, H, W, 64), -7.0, dtype=torch.bfloat16, device=dev)
+    xout2 = torch.full((B, H, W, 256), -7.0, dtype=torch.bfloat16, device=dev)
+    d.x_out = xout2.data_ptr()
+    d.a_out, d.a_out_elems, d.w2a, d.b2a = aout.data_ptr(), aout.numel(), wad.data_ptr(), bad.data_ptr()
+    handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    assert torch.equal(xout2, first), "x_out of the streamed form differs in %d elements" % int((xout2 != first).sum())
+    ea, sa = float((aout.cpu().double() - ao).abs().max()), max(1.0, float(ao.abs().max()))
+    print("a_out: max err %.3e of scale %.2f" % (ea, sa))
+    assert ea <= 1.5e-2 * sa
+    a1 = aout.clone()
+    for rep in range(3):
+        handle.check(L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)))
+    torch.cuda.synchronize()
+    assert torch.equal(a1, aout) and torch.equal(xout2, first)
+    d.a_out = ad.data_ptr()
+    assert L.lib.rtn_bottleneck64_fwd(handle.raw, C.byref(d)) == -1          # next-branch2a output aliasing this block's branch2a input
 
 
 def test_engine_with_fused_bottlenecks_matches_separate_layers(pkg):
@@ -165,6 +185,8 @@ def test_engine_with_fused_bottlenecks_matches_separate_layers(pkg):
         torch.cuda.synchronize()
         kinds = [op[0] for op in eng.active_ops(plan)]
         assert kinds.count("bneck") == (3 if fuse else 0)
+        names = [op[2] for op in eng.active_ops(plan)]
+        assert ("res2b_branch2a" in names) == (not fuse)      # rides along with res2a's fused block
         feats[fuse] = [t.float().cpu().clone() for t in plan["feats"]]
     for lvl, (a, b) in enumerate(zip(feats[False], feats[True])):
         scale = float(a.abs().max())
