@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChParams p) {
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int u = 0; u < PX; ++u)
-                        res[g][s][u] = (dbg & 1) ? make_uint4(0u, 0u, 0u, 0u) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u], g * 128 + s * 64, 0));
+                        res[g][s][u] = (dbg & 1) ? make_uint4(0u, 0u, 0u, 0u) : __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u], g * 128 + s * 64, 2));
 #pragma unroll
             for (int f = 0; f < 4 * N3; ++f)
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void chain1x1_kernel(const ChParams p) {
 #pragma unroll
                         for (int u = 0; u < PX; ++u)
                             res[(g + DEPTH) % (DEPTH + 1)][s][u] =
-                                __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u], (g + DEPTH) * 128 + s * 64, 0));
+                                __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff[u], (g + DEPTH) * 128 + s * 64, 2)     /* nt: the shortcut's last reader */);
                 }
                 f32x4 acc2[4][PX];
 #pragma unroll
