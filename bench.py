@@ -173,6 +173,9 @@ def train_algorithmic_bytes(eng, tr, bp, B, N, K, conv_bytes_fn):
             m = op[3]
             px = m["B"] * m["H"] * m["W"]
             groups["forward"] += 2.0 * px * (64 + 256 + 256 + 64 + (64 if m.get("tail") else 0))
+        elif op[0] == "chain":
+            m = op[3]
+            groups["forward"] += 2.0 * m["pixels"] * ((6 * m["mid"] + m["proj_c"]) if m.get("proj_c") else 10 * m["mid"])
         elif op[0] == "stem":
             Bn, Hn, Wn = op[2]
             groups["forward"] += Bn * (CANVAS[0] * CANVAS[1] * 4 * 2 + ((Hn + 1) // 2) * ((Wn + 1) // 2) * 64 * (2 + 2 + 1))
@@ -471,9 +474,9 @@ def main():
         def op_flops(op):
             if op[0] == "bneck":             # branch2b (3x3, 64 -> 64) + branch2c (64 -> 256) [+ the next branch2a (256 -> 64)]
                 m = op[3]
-                return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + (256 * 64 if (m["tail"] or m.get("proj")) else 0))
+                return 2.0 * m["B"] * m["H"] * m["W"] * (576 * 64 + 64 * 256 + 256 * 64 * (int(bool(m["tail"])) + int(bool(m.get("proj")))))
             if op[0] == "chain":             # branch2c (mid -> 4 mid) + the next branch2a (4 mid -> mid)
-                return 2.0 * op[3]["pixels"] * 2 * op[3]["mid"] * 4 * op[3]["mid"]
+                return 2.0 * op[3]["pixels"] * (2 * op[3]["mid"] + op[3].get("proj_c", 0)) * 4 * op[3]["mid"]      # proj_c: + the projection shortcut
             return conv_flops(op[1], BATCH) + (2.0 * BATCH * op[1].g[0].Hout * op[1].g[0].Wout * op[1].N * op[3].C if op[0] == "dual" else 0.0)
         flops_step = sum(op_flops(op) for op in conv_ops) + (conv_flops(stem_conv[1], BATCH) if fused_stem else 0.0)
         stem_op = [op for op in active if op[0] == "stem"]
@@ -505,11 +508,13 @@ def main():
             if op[0] == "bneck":             # a_in + shortcut in, x_out (+ a_out) out, the three filters
                 m = op[3]
                 px = m["B"] * m["H"] * m["W"]
-                if m.get("proj"):            # a_in + the block input in, x_out out, branch2b + the K-concatenated [branch2c | branch1] filters
-                    return 2.0 * (px * (64 + 64 + 256) + 576 * 64 + 128 * 256)
+                if m.get("proj"):            # a_in + the block input in, x_out (+ a_out) out, branch2b + the K-concatenated [branch2c | branch1] filters
+                    return 2.0 * (px * (64 + 64 + 256 + (64 if m["tail"] else 0)) + 576 * 64 + 128 * 256 + (256 * 64 if m["tail"] else 0))
                 return 2.0 * (px * (64 + 256 + 256 + (64 if m["tail"] else 0)) + 576 * 64 + 64 * 256 + (256 * 64 if m["tail"] else 0))
             if op[0] == "chain":             # branch2b's output + shortcut in, x_out + a_out out, the two filters
                 m = op[3]
+                if m.get("proj_c"):          # branch2b's output + the sampled block input in, x_out + a_out out, the filters
+                    return 2.0 * (m["pixels"] * (6 * m["mid"] + m["proj_c"]) + 4 * m["mid"] * (2 * m["mid"] + m["proj_c"]))
                 return 2.0 * (m["pixels"] * 10 * m["mid"] + 8 * m["mid"] * m["mid"])
             return conv_bytes(op[1], BATCH) + ((BATCH * op[3].Hin * op[3].Win * op[3].C + op[1].N * op[3].C) * 2.0 if op[0] == "dual" else 0.0)
         bytes_step = sum(op_bytes(op) for op in conv_ops)

@@ -32,11 +32,11 @@ for (kind, ms), op in zip(per, eng.active_ops(plan) + [("detect",)]):
     ms /= reps; tot += ms
     if kind == "bneck":
         m = op[3]; px = m["B"] * m["H"] * m["W"]
-        fl = 2.0 * px * (576 * 64 + 64 * 256 + (256 * 64 if (m["tail"] or m.get("proj")) else 0))
-        by = 2.0 * px * ((64 + 64 + 256) if m.get("proj") else (64 + 256 + 256 + (64 if m["tail"] else 0)))
+        fl = 2.0 * px * (576 * 64 + 64 * 256 + 256 * 64 * (int(bool(m["tail"])) + int(bool(m.get("proj")))))
+        by = 2.0 * px * ((64 + 64 + 256 + (64 if m["tail"] else 0)) if m.get("proj") else (64 + 256 + 256 + (64 if m["tail"] else 0)))
         print("%-28s %9.4f %9.2f %8.1f  fused bottleneck M=%d, %.0f MB -> %.2f TB/s" % (op[2], ms, fl / 1e9, fl / ms / 1e9, px, by / 1e6, by / ms / 1e9))
     elif kind == "chain":
-        m = op[3]; fl = 2.0 * m["pixels"] * 8 * m["mid"] * m["mid"]; by = 2.0 * m["pixels"] * 10 * m["mid"]
+        m = op[3]; pc = m.get("proj_c", 0); fl = 2.0 * m["pixels"] * (2 * m["mid"] + pc) * 4 * m["mid"]; by = 2.0 * m["pixels"] * ((6 * m["mid"] + pc) if pc else 10 * m["mid"])
         print("%-28s %9.4f %9.2f %8.1f  fused seam M=%d, %.0f MB -> %.2f TB/s" % (op[2], ms, fl / 1e9, fl / ms / 1e9, m["pixels"], by / 1e6, by / ms / 1e9))
     elif kind in ("conv", "dual", "conv8", "convq"):
         d = op[1]; fl = bench.conv_flops(d, B)
