@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
     const int m = lane & 15, kq = lane >> 4;
     constexpr int PCH = PA_H * (PA_ROW / 16);             // 828 chunks of 16 B per patch
     constexpr int NPF = (PCH + 255) / 256;                // 4 per thread
-    constexpr int KH_UNROLL = A2 ? 1 : 7;
+    constexpr int KH_UNROLL = 7;
 
     for (int i = t; i < 64 * 28; i += 256) {
         const int n = i / 28, q = i - n * 28;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(const StemParams p) 
         for (int s = 0; s < SUB_PER_WAVE; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[s][j] = *reinterpret_cast<const f32x4*>(wl + (4 * j + kq) * W_ROW + 7 * 64);     // bias-initialised, as every conv kernel of the library
-#pragma unroll KH_UNROLL     // A2: the fully unrolled loop hoists all 28 filter fragments and spills beside the branch2a state
-        for (int kh = 0; kh < 7; ++kh) {        // (reading the fragments of row kh + 1 under the MFMAs of row kh measured no faster)
+#pragma unroll KH_UNROLL     // fully unrolled in every form since the BN shifts moved into the filter rows' LDS pads (round 4: the A2 form used to
+        for (int kh = 0; kh < 7; ++kh) {        // spill and ran the loop rolled: 0.110 -> 0.098 ms)
             uint4 bf[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const uint4*>(wl + (j * 16 + m) * W_ROW + kh * 64 + kq * 16);
