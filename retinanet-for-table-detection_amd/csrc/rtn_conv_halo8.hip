@@ -65,6 +65,8 @@ struct H8Group {
     unsigned in_bytes, out_bytes, res_bytes, mask_bytes;
     int Hin, Win, M, tile_begin;
     int in_row_stride_b;
+    int in_img_pad_b;             // bytes between the end of one image of `in` and the start of the next (0: dense; the data gradient of a
+                                  // head output reads one level out of the level-concatenated dY)
     float inv_cells, inv_w;
 };
 
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(H8_THREADS, 2) void conv_halo8_kernel(const H8Param
                 divmod24(f, cells, Gs.inv_cells, b, rem);
                 divmod24(rem, Gs.Win, Gs.inv_w, y, x);
                 hiy[i] = y;
-                hbase[i] = (unsigned)f * (unsigned)p.pix_b + (unsigned)sc * 16u;
+                hbase[i] = (unsigned)f * (unsigned)p.pix_b + (unsigned)b * (unsigned)Gs.in_img_pad_b + (unsigned)sc * 16u;
             } else {
                 hiy[i] = -(1 << 28);
                 hbase[i] = 0;
@@ -804,7 +806,8 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
     for (int i = 0; i < d->ngroups; ++i) {
         const rtn_conv_group_t& s = d->g[i];
         if (s.Hin != s.Hout || s.Win != s.Wout || s.in_row_stride != (long long)s.Win * d->pix_stride ||
-            s.in_img_stride != (long long)s.Hin * s.in_row_stride) return 1;
+            s.in_img_stride < (long long)s.Hin * s.in_row_stride) return 1;
+        if (s.in_elems < (long long)(d->batch - 1) * s.in_img_stride + (long long)s.Hin * s.in_row_stride) return 1;
         const long long cells = (long long)s.Hout * s.Wout, M = cells * d->batch;
         if (s.out_step > 1 || s.out_off != 0 || s.out_img_stride != cells * d->out_ld) return 1;      // dense [M][out_ld] output
         if (M >= (1ll << 24) || M < 1) return 1;
@@ -833,6 +836,7 @@ int rtn_conv_halo8_try(rtn_handle_t h, const rtn_conv_desc_t* d, int grid_limit,
         g.Hin = s.Hin; g.Win = s.Win; g.M = (int)M;
         g.tile_begin = (int)tiles;
         g.in_row_stride_b = (int)(s.in_row_stride * es);
+        g.in_img_pad_b = (int)((s.in_img_stride - (long long)s.Hin * s.in_row_stride) * es);
         g.inv_cells = 1.0f / (float)cells;
         g.inv_w = 1.0f / (float)s.Win;
         tiles += (M + TM - 1) / TM;

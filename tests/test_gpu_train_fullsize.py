@@ -131,7 +131,7 @@ EXPECTED_IMPLS = {
     ("dgrad", "res4b_branch2a"): 5, ("dgrad", "res4b_branch2b"): 4, ("dgrad", "res4b_branch2c"): 5,
     ("dgrad", "res5b_branch2a"): 5, ("dgrad", "res5b_branch2b"): 2, ("dgrad", "res5b_branch2c"): 5,
     ("dgrad", "res2b_branch2b"): 2, ("dgrad", "res2b_branch2c"): 1, ("dgrad", "P6"): 2, ("dgrad", "P7"): 1,
-    ("dgrad", "pyramid_regression"): 2, ("dgrad", "pyramid_classification"): 2,
+    ("dgrad", "pyramid_regression"): 4, ("dgrad", "pyramid_classification"): 4,
     # weight gradients: the nine-tap window kernel for the stride-1 3x3 layers (towers, P3, P4, res3-res5 branch2b; its 64-filter
     # form for res2 branch2b and the head outputs), the 256 x 256 LDS-DMA kernel for the 1x1 layers with >= 2048 pixel tiles (C3_reduced, res3a_branch1), the
     # 128 x 128 LDS-DMA kernel for the rest
