@@ -62,12 +62,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __u
 template <int SRC, int DST>
 __global__ __launch_bounds__(256) void stem_pack_kernel(const void* __restrict__ src, void* __restrict__ dst, int B, int H,
                                                         int W, int Hp, int Wp) {
-    // grid: x = pixels of a packed row, y = packed rows of the batch (strided): no 64-bit division per pixel
-    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (x >= Wp) return;
-    for (int row = blockIdx.y; row < B * Hp; row += gridDim.y) {
-        const int b = row / Hp, y = row - b * Hp;
-        const long long i = (long long)row * Wp + x;
+    const long long total = (long long)B * Hp * Wp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wp);
+        const long long r = i / Wp;
+        const int y = (int)(r % Hp);
+        const int b = (int)(r / Hp);
         float v[3] = {0.f, 0.f, 0.f};
         const int sy = y - 3, sx = x - 3;
         if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
@@ -181,9 +181,8 @@ extern "C" int rtn_stem_pack(rtn_handle_t h, const void* src, int src_dtype, voi
         return rtn_fail(h, RTN_EINVAL, "stem_pack: bad dtype");
     if (Hp < H + 6 || Wp < W + 6 || (Wp & 1)) return rtn_fail(h, RTN_EINVAL, "stem_pack: padded extent %dx%d too small for %dx%d", Hp, Wp, H, W);
     if ((uintptr_t)dst & 15) return rtn_fail(h, RTN_EINVAL, "stem_pack: dst not 16-byte aligned");
-    const long long rows = (long long)B * Hp;
-    if (rows >= (1ll << 31)) return rtn_fail(h, RTN_EINVAL, "stem_pack: extent");
-    dim3 g((unsigned)((Wp + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535)), b(256);
+    const long long total = (long long)B * Hp * Wp;
+    dim3 g(grid_for(total)), b(256);      // (a 2-D grid without the 64-bit divisions measured slower in the step: 36 us against 25)
 #define LAUNCH(S, D) hipLaunchKernelGGL((stem_pack_kernel<S, D>), g, b, 0, h->stream, src, dst, B, H, W, Hp, Wp)
     if (dst_dtype == RTN_BF16) {
         if (src_dtype == 0) LAUNCH(0, RTN_BF16); else if (src_dtype == 1) LAUNCH(1, RTN_BF16); else LAUNCH(2, RTN_BF16);

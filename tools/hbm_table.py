@@ -57,7 +57,7 @@ entries = [   # (kernel, where, bytes per step, launches per step or None = from
     ("adam_kernel<2>", "train", tr.NW * (6 * 4 + 3 * 4 + 2)),
     ("adam_kernel<4>", "train", tr.NB * (6 * 4 + 3 * 4 + 4)),
     ("maxpool_bwd_idx_kernel<2>", "train", B * (Hp * Wp * 64 * (2 + 1 + 2) + H1 * W1 * 64 * 2)),
-    ("pad_cast_rows_kernel<2>", "train", padcast),
+    ("pad_cast_rows8_kernel", "train", padcast),
     ("wgrad_finish_kernel (all instances)", "train", finish_bytes),
     ("pack_dgrad_multi_kernel<unsigned short>", "train", packd),
     ("stem_pack_kernel<0, 0>", "infer", bench.BATCH * (H * W * 3 * 2 + xi["Hp"] * xi["Wp"] * 4 * 2)),
