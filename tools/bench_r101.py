@@ -1,7 +1,7 @@
 """BASELINE.json configs[4] shape: ResNet-101-FPN, 1024x1024 pages, batch 8.  bf16 throughout, or with --fp8-towers the two head
 towers (38 % of the FLOPs) in fp8 e4m3 after a one-batch calibration (Engine.calibrate_fp8); the backbone and FPN stay bf16.
 --fp8-backbone adds every 3x3 branch2b layer with >= 128 channels (another 30 % of the FLOPs).
-  python tools/bench_r101.py [resnet101|resnet152] [side] [--fp8-towers] [--fp8-backbone]     prints images/s and the conv TFLOP/s."""
+  python tools/bench_r101.py [resnet101|resnet152] [side] [--fp8-towers] [--fp8-backbone] [--in-flight-2]     prints images/s and the conv TFLOP/s."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch, bench
@@ -17,10 +17,11 @@ eng = E.Engine(backbone, 1, 9, dtype="bf16"); eng.load_state(state)
 g = torch.Generator().manual_seed(1)
 x = (torch.rand(B, H, W, 3, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
 if fp8: eng.calibrate_fp8(x, backbone=fp8b)
+if "--in-flight-2" in sys.argv: eng.in_flight = 2
 for _ in range(3): eng.detect(x)
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 20
 for _ in range(n): eng.detect(x)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+eng.join(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 plan = eng._plan(B, H, W)
 fl = sum(bench.conv_flops(op[1], B) for op in plan["ops"] if op[0] in ("conv", "conv8", "convq"))
 print("%s %dx%d batch %d %s: %.3f ms/step = %.1f img/s; %.1f GFLOP/image; %.0f TFLOP/s over the step; anchors %d"
