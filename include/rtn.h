@@ -238,7 +238,7 @@ typedef struct {
 } rtn_bottleneck_desc_t;
 int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d);
 
-/* The seam between two keras_resnet identity bottleneck blocks of the 128- / 256-channel stages (res3b..d, res4b..f) as ONE
+/* The seam between two keras_resnet identity bottleneck blocks of the 128-channel stage (res3b..d) as ONE
  * launch (inference and training forward, bf16):
  *   x_out = relu(conv1x1(h_in;  w2c) + b2c + x_in)          this block's branch2c + BN + Add + ReLU   (mid -> out = 4 mid)
  *   a_out = relu(conv1x1(x_out; w2a) + b2a)                 the NEXT block's branch2a + BN + ReLU     (out -> next = mid)
@@ -247,7 +247,7 @@ int rtn_bottleneck64_fwd(rtn_handle_t h, const rtn_bottleneck_desc_t* d);
  * back.  Tensors are dense [pixels][channels] bf16 (NHWC with batch x H x W flattened: the two convs are pointwise, stride 1),
  * weights [N][K] K-contiguous, biases f32.  Roundings are those of the two separate launches (x_out is rounded to bf16 before it is
  * multiplied again) and so is the f32 summation order: the results are bit-identical to them.
- * Built for (mid, out, next) = (128, 512, 128) and (256, 1024, 256): rtn_chain1x1_supported. */
+ * Built for (mid, out, next) = (128, 512, 128): rtn_chain1x1_supported. */
 typedef struct {
     const void* h_in;  int64_t h_in_elems;    /* [pixels][mid]                            */
     const void* x_in;  int64_t x_in_elems;    /* [pixels][out]   shortcut                 */

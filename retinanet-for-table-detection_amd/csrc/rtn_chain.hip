@@ -1,4 +1,4 @@
-// rtn_chain.hip — the seam between two keras_resnet identity bottleneck blocks of the 128- and 256-channel stages as ONE kernel:
+// rtn_chain.hip — the seam between two keras_resnet identity bottleneck blocks of the 128-channel stage as ONE kernel:
 //   x_out = relu(conv1x1(h_in; w2c) + b2c + x_in)      this block's branch2c + BN + Add + ReLU   (mid -> 4 mid)
 //   a_out = relu(conv1x1(x_out; w2a) + b2a)            the NEXT block's branch2a + BN + ReLU     (4 mid -> mid)
 // (keras_resnet bottleneck_2d as instantiated by model/defineModel.py:376-380; the reference runs these as two Conv2D, two
@@ -9,7 +9,7 @@
 // Same chaining as rtn_bottleneck.hip: both products are computed TRANSPOSED (weights = the MFMA's A operand, pixels = its
 // columns) with the weight rows permuted so that the bf16-packed accumulators of the first product ARE the B operand of the second
 // and are also what a 16-byte store wants (8 consecutive channels of a pixel).  What differs: the filters do not fit the LDS
-// (res3: 2 x 128 KB, res4: 2 x 512 KB), so they are STREAMED through it in chunks of 64 branch2c output channels = 64 K values of
+// (2 x 128 KB; 2 x 512 KB at 256 channels), so they are STREAMED through it in chunks of 64 branch2c output channels = 64 K values of
 // the next branch2a: chunk g needs rows [64 g, 64 g + 64) of w2c (all of its K) and columns [64 g, 64 g + 64) of w2a (all of its
 // rows).  All waves of a workgroup walk the chunks in step (one barrier per chunk, LDS double buffer, the next chunk's filters
 // loaded into registers at the start of a chunk and written to the other buffer at its end); a wave owns a strip of 16 PX pixels,
@@ -255,7 +255,7 @@ int chain_launch(rtn_handle_t h, ChParams& p, int grid_limit) {
 }  // namespace
 
 extern "C" int rtn_chain1x1_supported(int mid, int out, int next) {
-    return (mid == 128 && out == 512 && next == 128) || (mid == 256 && out == 1024 && next == 256);
+    return mid == 128 && out == 512 && next == 128;    // (a 256 -> 1024 -> 256 instance was built and measured no faster than its two launches: profiles/r4_seam_kernel.txt)
 }
 
 extern "C" int rtn_chain1x1_fwd(rtn_handle_t h, const rtn_chain_desc_t* d) {
@@ -264,7 +264,7 @@ extern "C" int rtn_chain1x1_fwd(rtn_handle_t h, const rtn_chain_desc_t* d) {
     if (!d) return rtn_fail(h, RTN_EINVAL, "chain1x1: null descriptor");
     if (d->dtype != RTN_BF16) return rtn_fail(h, RTN_EINVAL, "chain1x1: bf16 only");
     if (!rtn_chain1x1_supported(d->mid, d->out, d->next))
-        return rtn_fail(h, RTN_EINVAL, "chain1x1: built for 128 -> 512 -> 128 and 256 -> 1024 -> 256 channels, got %d -> %d -> %d", d->mid, d->out, d->next);
+        return rtn_fail(h, RTN_EINVAL, "chain1x1: built for 128 -> 512 -> 128 channels, got %d -> %d -> %d", d->mid, d->out, d->next);
     const long long M = d->pixels;
     if (M < 1) return rtn_fail(h, RTN_EINVAL, "chain1x1: empty extent");
     if (M * d->out * 2 >= (1ll << 31)) return rtn_fail(h, RTN_EINVAL, "chain1x1: %lld pixels x %d channels exceed the 2 GiB tensor range", M, d->out);
@@ -285,6 +285,5 @@ extern "C" int rtn_chain1x1_fwd(rtn_handle_t h, const rtn_chain_desc_t* d) {
     const int gl = rtn_env_int("RTN_CHAIN_GRID", 0);             // tests: several passes per workgroup on small inputs
     // (shortcut fragments two chunks ahead instead of one, and x_out as whole lines through an LDS transpose as in rtn_bottleneck.hip,
     // measured no faster: this kernel is not bound by bytes in flight or by the texture addresser)
-    if (d->mid == 128) return chain_launch<2, 8, 2, 2, 1>(h, p, gl);
-    return chain_launch<4, 16, 4, 1, 1>(h, p, gl);
+    return chain_launch<2, 8, 2, 2, 1>(h, p, gl);
 }

@@ -106,11 +106,9 @@ class Engine:
         self.fuse_bottleneck = os.environ.get("RTN_FUSE_BOTTLENECK", "1") != "0"
         # ... and res2b_branch2a appended to res2a's fused block (its projection form with the three per-chunk filter sets streamed)
         self.fuse_proj_tail = os.environ.get("RTN_FUSE_PROJ_TAIL", "1") != "0"
-        # bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128- and
-        # 256-channel stages (rtn_chain1x1_fwd)
-        # (bit 0: the 128-channel stage, bit 1: the 256-channel stage - built and bit-exact, but no faster than its two layers at 16-pixel
-        # strips, where the filter stream through the LDS bounds it: off by default, tools/ab_engine.py)
-        self.fuse_chain = int(os.environ.get("RTN_FUSE_CHAIN", "1")) & 3
+        # bf16: an identity block's branch2c + Add + ReLU and the next block's branch2a as one launch in the 128-channel stage
+        # (rtn_chain1x1_fwd; the 256-channel instance measured no faster and left the library: profiles/r4_seam_kernel.txt)
+        self.fuse_chain = os.environ.get("RTN_FUSE_CHAIN", "1") != "0"
         self.weights_version = 0
         self.load_epoch = 0            # bumped by load_state(): a live Trainer re-derives its master copy / plans from it
         self._dual, self._dual_version = {}, -1
@@ -589,15 +587,13 @@ class Engine:
         for fs in (0, 1, 2):                             # fuse_stem: 1 = conv1 + ReLU + pool1, 2 = ... + res2a_branch2a
             for fd in (False, True):                     # fuse_shortcut
                 for fk in ((0, 1, 2) if bneck_ok else (0,)):      # fuse_bottleneck: 1 = inference, 2 = training (branch2b's output is kept)
-                  for fc in ((0, 1, 2, 3) if (bneck_ok and seams) else (0,)):      # fuse_chain: bit 0 = stage 3, bit 1 = stage 4
+                  for fc in ((0, 1) if (bneck_ok and seams) else (0,)):      # fuse_chain
                    for fp in ((0, 1) if (fk and fd) else (0,)):                    # fuse_proj_tail
                     if not fs and not fd and not fk and not fc:
                         continue
                     v = list(ops)
                     if fc:
                         for sm in seams:
-                            if not (fc & (1 if sm["f"] == 128 else 2)):
-                                continue
                             v[sm["i_2c"]] = self._chain_op(sm)
                             v[sm["i_2a"]] = None
                     if fd:
@@ -782,7 +778,7 @@ class Engine:
             fk = 2 if self.training else 1               # training: the fused blocks also store branch2b's output for the backward pass
         fs = (2 if self.fuse_stem_2a else 1) if (self.fuse_stem and stem16) else 0
         # (training too: both tensors of a seam are written, which is all the backward pass reads)
-        fc = (int(self.fuse_chain) & 3) if (self.dtype == "bf16" and not self._fp8_on()) else 0
+        fc = 1 if (self.fuse_chain and self.dtype == "bf16" and not self._fp8_on()) else 0
         fp = 1 if (self.fuse_proj_tail and fk and self.fuse_shortcut) else 0
         key = (fs, self.fuse_shortcut, fk, fc, fp)
         return key if any(key) else None

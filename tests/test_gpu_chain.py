@@ -39,8 +39,7 @@ def conv1x1(L, handle, x, out, w, b, n, k, flags, res=None):
     return ws
 
 
-@pytest.mark.parametrize("mid,M,grid", [(128, 1, 0), (128, 37, 0), (128, 2 * 25 * 42, 0), (128, 8 * 31 * 33, 3), (128, 5000, 1),
-                                        (256, 1, 0), (256, 130, 0), (256, 2 * 13 * 21, 0), (256, 3111, 2), (256, 2049, 1)])
+@pytest.mark.parametrize("mid,M,grid", [(128, 1, 0), (128, 37, 0), (128, 2 * 25 * 42, 0), (128, 8 * 31 * 33, 3), (128, 5000, 1), (128, 2049, 2)])
 def test_chain1x1_kernel(pkg, handle, monkeypatch, mid, M, grid):
     L = pkg._lib
     if grid:                                       # RTN_CHAIN_GRID: several passes per workgroup, the filter stream wraps around
@@ -66,7 +65,7 @@ def test_chain1x1_kernel(pkg, handle, monkeypatch, mid, M, grid):
     d.x_out, d.x_out_elems, d.a_out, d.a_out_elems = xout.data_ptr(), xout.numel(), aout.data_ptr(), aout.numel()
     d.w2c, d.b2c, d.w2a, d.b2a = wcd.data_ptr(), bcd.data_ptr(), wad.data_ptr(), bad.data_ptr()
     d.pixels, d.mid, d.out, d.next, d.dtype = M, mid, out, mid, L.RTN_BF16
-    assert L.lib.rtn_chain1x1_supported(mid, out, mid) == 1 and L.lib.rtn_chain1x1_supported(64, 256, 64) == 0
+    assert L.lib.rtn_chain1x1_supported(mid, out, mid) == 1 and L.lib.rtn_chain1x1_supported(64, 256, 64) == 0 and L.lib.rtn_chain1x1_supported(256, 1024, 256) == 0
     handle.check(L.lib.rtn_chain1x1_fwd(handle.raw, C.byref(d)))
     torch.cuda.synchronize()
     first = (xout.clone(), aout.clone())
@@ -107,8 +106,8 @@ def test_chain1x1_kernel(pkg, handle, monkeypatch, mid, M, grid):
 
 
 def test_engine_with_fused_seams_gives_the_bits_of_separate_layers(pkg, monkeypatch):
-    """Engine level (inference, bf16): with Engine.fuse_chain the op list holds one "chain" op per identity-block seam of stages 3
-    and 4 (2 + 4 at ResNet-50) instead of a branch2c and a branch2a conv, and every feature map, the regression and the
+    """Engine level (inference, bf16): with Engine.fuse_chain the op list holds one "chain" op per identity-block seam of stage 3
+    (2 at ResNet-50) instead of a branch2c and a branch2a conv, and every feature map, the regression and the
     classification tensors carry the SAME BITS as with the layers launched separately on generation 5 (RTN_CONV_IMPL=5: the kernel
     those layers take at the bench size; the small canvas of this test would otherwise send them to generation 2, whose f32
     summation order differs)."""
@@ -122,7 +121,7 @@ def test_engine_with_fused_seams_gives_the_bits_of_separate_layers(pkg, monkeypa
     eng.load_state(state)
     got = {}
     for fuse in (False, True):
-        eng.fuse_chain = 3 if fuse else 0
+        eng.fuse_chain = fuse
         plan = eng._plan(2, 320, 448)
         for t in plan["feats"]:
             t.fill_(-7.0)
@@ -130,12 +129,12 @@ def test_engine_with_fused_seams_gives_the_bits_of_separate_layers(pkg, monkeypa
         torch.cuda.synchronize()
         ops = eng.active_ops(plan)
         names = [op[2] for op in ops if op[0] in ("conv", "chain")]
-        assert [op[0] for op in ops].count("chain") == (6 if fuse else 0)
-        assert ("res3c_branch2a" in names) == (not fuse) and ("res4b_branch2c" in names) == (not fuse)
+        assert [op[0] for op in ops].count("chain") == (2 if fuse else 0)
+        assert ("res3c_branch2a" in names) == (not fuse) and ("res3b_branch2c" in names) == (not fuse) and "res4b_branch2c" in names
         assert "res3b_branch2a" in names and "res3d_branch2c" in names       # the seam behind the projection block / the stage's end stay convs
         got[fuse] = [t.clone() for t in plan["feats"]] + [reg.clone(), cls.clone()]
     for a, b in zip(got[False], got[True]):
         assert float(a.float().abs().max()) > 0.01 and torch.equal(a, b)
     eng.training = True                              # the training forward takes the same fused seams
-    assert [op[0] for op in eng.active_ops(eng._plan(2, 320, 448))].count("chain") == 6
+    assert [op[0] for op in eng.active_ops(eng._plan(2, 320, 448))].count("chain") == 2
     eng.training = False
